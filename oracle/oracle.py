@@ -1,0 +1,199 @@
+"""Python face of the CPU oracle (TEST INFRASTRUCTURE -- see the header of oracle.c).
+
+PARITY UNPINNED against PySCF: the reference's arithmetic lives in un-vendored
+pyscf==2.8.0 / gpu4pyscf; nothing here was checked against them in this environment.
+
+The SCF loop restates the control flow PySCF's `scf.hf.kernel` is documented to follow [MEM]
+(call site in the reference: `templates/calculate_energy.py:205` `mf.kernel()`):
+core guess/dm0 -> get_veff -> loop { Fock (+CDIIS, space 8, start cycle 1) -> eig(F,S) -> aufbau ->
+dm -> get_veff -> E_tot ; converge on |dE| < conv_tol and |g|/sqrt(n) < sqrt(conv_tol) } -> one extra
+cycle.  numpy + liboracle.so only.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.orc_jk_direct.restype = ctypes.c_long
+    return _LIB
+
+
+def _p(a, t=ctypes.c_double):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+class Oracle:
+    def __init__(self, mol):
+        self.mol = mol
+        self.atm = np.ascontiguousarray(mol._atm, dtype=np.int32)
+        self.bas = np.ascontiguousarray(mol._bas, dtype=np.int32)
+        self.env = np.ascontiguousarray(mol._env, dtype=np.float64)
+        self.natm, self.nbas, self.nao = len(self.atm), len(self.bas), mol.nao
+        rc = lib().orc_check(_p(self.bas, ctypes.c_int), self.nbas)
+        if rc != 0:
+            raise ValueError(f"oracle cannot handle this basis (code {rc})")
+
+    def _args(self):
+        return (_p(self.atm, ctypes.c_int), self.natm, _p(self.bas, ctypes.c_int), self.nbas, _p(self.env))
+
+    def int1e(self, origin=None):
+        n = self.nao
+        S, T, V = (np.zeros((n, n)) for _ in range(3))
+        dip = np.zeros((3, n, n))
+        org = np.zeros(3) if origin is None else np.ascontiguousarray(origin, dtype=np.float64)
+        lib().orc_int1e(*self._args(), _p(S), _p(T), _p(V), _p(dip), _p(org))
+        return S, T, V, dip
+
+    def schwarz(self):
+        q = np.zeros((self.nbas, self.nbas))
+        lib().orc_schwarz(*self._args(), _p(q))
+        return q
+
+    def eri_full(self):
+        n = self.nao
+        if n > 80:
+            raise MemoryError("eri_full is for small test molecules")
+        eri = np.zeros((n, n, n, n))
+        lib().orc_eri_full(*self._args(), _p(eri))
+        return eri
+
+    def eri_shell(self, i, j, k, l):
+        d = [2 * int(self.bas[s, 1]) + 1 for s in (i, j, k, l)]
+        out = np.zeros(d)
+        lib().orc_eri_shell(*self._args(), int(i), int(j), int(k), int(l), _p(out))
+        return out
+
+    def jk(self, dm, tol=1e-13):
+        n = self.nao
+        dm = np.ascontiguousarray(dm, dtype=np.float64)
+        J, K = np.zeros((n, n)), np.zeros((n, n))
+        nq = lib().orc_jk_direct(*self._args(), _p(dm), _p(J), _p(K), ctypes.c_double(tol))
+        self.last_nquartets = nq
+        return J, K
+
+    @staticmethod
+    def num_threads():
+        return lib().orc_num_threads()
+
+
+# ------------------------------------------------------------------------------------------------
+
+class CDIIS:
+    """Pulay DIIS on e = SDF - FDS, subspace 8 (PySCF `scf.diis.CDIIS` defaults [MEM])."""
+
+    def __init__(self, space=8):
+        self.space = space
+        self.f, self.e = [], []
+
+    def update(self, s, d, f):
+        sdf = s @ d @ f
+        err = (sdf.T - sdf).ravel()
+        self.f.append(f.copy())
+        self.e.append(err)
+        if len(self.f) > self.space:
+            self.f.pop(0)
+            self.e.pop(0)
+        m = len(self.f)
+        B = np.zeros((m + 1, m + 1))
+        B[0, 1:] = B[1:, 0] = 1.0
+        for i in range(m):
+            for j in range(i + 1):
+                B[i + 1, j + 1] = B[j + 1, i + 1] = self.e[i] @ self.e[j]
+        rhs = np.zeros(m + 1)
+        rhs[0] = 1.0
+        try:
+            c = np.linalg.solve(B, rhs)
+        except np.linalg.LinAlgError:
+            c = np.linalg.lstsq(B, rhs, rcond=None)[0]
+        return sum(ci * fi for ci, fi in zip(c[1:], self.f))
+
+
+def eig_gen(f, s):
+    """FC = SCe by Loewdin-free canonical route: Cholesky of S."""
+    L = np.linalg.cholesky(s)
+    Li = np.linalg.inv(L)
+    e, c = np.linalg.eigh(Li @ f @ Li.T)
+    return e, Li.T @ c
+
+
+def rhf(mol, dm0=None, conv_tol=1e-9, max_cycle=50, veff_fn=None, verbose=False, jk_tol=1e-13):
+    """Closed-shell SCF.  `veff_fn(dm) -> (vhf, e_extra_xc_minus_trace_correction)` lets the RKS oracle
+    reuse the loop; default is RHF: vhf = J - K/2."""
+    orc = Oracle(mol)
+    S, T, V, _ = orc.int1e()
+    h = T + V
+    enuc = mol.energy_nuc()
+    nocc = mol.nelectron // 2
+
+    def make_dm(c):
+        co = c[:, :nocc]
+        return 2.0 * co @ co.T
+
+    if veff_fn is None:
+        def veff_fn(dm):
+            J, K = orc.jk(dm, jk_tol)
+            return J - 0.5 * K, None
+
+    def energy(dm, vhf, exc):
+        e1 = float(np.sum(dm * h))
+        if exc is None:
+            e2 = 0.5 * float(np.sum(dm * vhf))
+        else:
+            e2 = exc  # veff_fn returns the full two-electron energy (Coulomb + xc) itself
+        return e1 + e2 + enuc
+
+    if dm0 is None:
+        e, c = eig_gen(h, S)
+        dm = make_dm(c)
+    else:
+        dm = np.array(dm0, dtype=np.float64)
+    vhf, exc = veff_fn(dm)
+    e_tot = energy(dm, vhf, exc)
+    diis = CDIIS()
+    conv_tol_grad = np.sqrt(conv_tol)
+    converged = False
+    mo_e = mo_c = None
+    cycles = 0
+    for cycle in range(max_cycle):
+        f = h + vhf
+        if cycle >= 1:
+            f = diis.update(S, dm, f)
+        mo_e, mo_c = eig_gen(f, S)
+        dm = make_dm(mo_c)
+        vhf, exc = veff_fn(dm)
+        e_last, e_tot = e_tot, energy(dm, vhf, exc)
+        f = h + vhf
+        g = 2.0 * mo_c[:, nocc:].T @ f @ mo_c[:, :nocc]
+        gnorm = np.linalg.norm(g) / np.sqrt(max(g.size, 1))
+        cycles = cycle + 1
+        if verbose:
+            print(f"oracle cycle {cycles:3d}  E = {e_tot:.12f}  dE = {e_tot - e_last: .3e}  |g| = {gnorm:.3e}")
+        if abs(e_tot - e_last) < conv_tol and gnorm < conv_tol_grad:
+            converged = True
+            break
+    if converged:  # one extra cycle (PySCF conv_check)
+        mo_e, mo_c = eig_gen(h + vhf, S)
+        dm = make_dm(mo_c)
+        vhf, exc = veff_fn(dm)
+        e_tot = energy(dm, vhf, exc)
+    mo_occ = np.zeros(len(mo_e))
+    mo_occ[:nocc] = 2.0
+    return dict(e_tot=e_tot, converged=converged, mo_energy=mo_e, mo_coeff=mo_c, mo_occ=mo_occ, dm=dm,
+                cycles=cycles, S=S, h=h, vhf=vhf)
