@@ -1,0 +1,1360 @@
+// mi355scf.hip -- MI355X (gfx950 / CDNA4) SCF Fock-build engine: C ABI + HIP kernels.
+//
+// See include/mi355scf.h for the boundary and DESIGN.md for the data layout.  Kernels:
+//   int1e_kernel            S, T, V, dipole (Obara-Saika overlap recurrences + Rys nuclear attraction)
+//   eri_rys_kernel          contracted [e0|f0] integrals by Rys quadrature, one wave per shell quartet,
+//                           2-D recurrence tables staged in LDS
+//   eri_transform_scatter   HRR + cart->sph as two small dense products, scatter into 8^4 AO tiles
+//   schwarz_diag_kernel     q_ab = sqrt(max (ab|ab))                      (row a3)
+//   jk_tiles_kernel         one-pass J+K digestion of the HBM-resident tiles (rows a5, a6)
+//   pad/finalize, DIIS helpers                                             (row a10)
+// Written for gfx950 only: 64-lane waves are assumed throughout.
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355scf.h"
+#include "rys_tables.h"
+
+#define LMAX 3
+#define NPC ((LMAX + 1) * (LMAX + 2) / 2) /* pair classes (la>=lb) */
+#define BLK 8
+#define ATM_SLOTS 6
+#define BAS_SLOTS 8
+
+static thread_local std::string g_err;
+static int fail(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *mi_last_error(void) { return g_err.c_str(); }
+extern "C" int mi_abi_version(void) { return 1; }
+
+// =================================================================================================
+// Real solid harmonics (generic l): coefficients of the unit-normalised real harmonics r^l Y_lm in
+// monomials x^a y^b z^c; order m=-l..l, except l=1 -> (x,y,z) (PySCF AO convention [MEM]).
+// Formula: Helgaker, Jorgensen, Olsen, "Molecular Electronic-Structure Theory", eq. 6.4.47-6.4.50.
+// =================================================================================================
+static inline int ncart(int l) { return (l + 1) * (l + 2) / 2; }
+static inline int cart_index(int l, int lx, int ly) /* order: lx desc, then ly desc */
+{
+    int n = 0;
+    for (int x = l; x > lx; x--) n += l - x + 1;
+    return n + (l - lx - ly);
+}
+static double fact(int n) { double f = 1; for (int i = 2; i <= n; i++) f *= i; return f; }
+static double binom(int n, int k) { if (k < 0 || k > n) return 0; return fact(n) / (fact(k) * fact(n - k)); }
+
+static void c2s_generic(int l, std::vector<double> &out) /* [ncart][2l+1] */
+{
+    int nc = ncart(l), ns = 2 * l + 1;
+    out.assign((size_t)nc * ns, 0.0);
+    for (int m = -l; m <= l; m++) {
+        int am = std::abs(m);
+        double N = 1.0 / (std::pow(2.0, am) * fact(l)) * std::sqrt(2.0 * fact(l + am) * fact(l - am) / (m == 0 ? 2.0 : 1.0));
+        N *= std::sqrt((2 * l + 1) / (4.0 * M_PI));
+        int col = (l == 1) ? (m == 1 ? 0 : (m == -1 ? 1 : 2)) : (m + l);
+        for (int t = 0; t <= (l - am) / 2; t++)
+            for (int u = 0; u <= t; u++) {
+                /* v = vm, vm+1, ... with 2v <= am ; vm = 0 (m>=0) or 1/2 (m<0): use v2 = 2v */
+                for (int v2 = (m < 0 ? 1 : 0); v2 <= am; v2 += 2) {
+                    double C = std::pow(-1.0, t + (v2 - (m < 0 ? 1 : 0)) / 2) * std::pow(0.25, t) * binom(l, t) *
+                               binom(l - t, am + t) * binom(t, u) * binom(am, v2);
+                    int px = 2 * t + am - 2 * u - v2, py = 2 * u + v2, pz = l - 2 * t - am;
+                    if (px < 0 || py < 0 || pz < 0) continue;
+                    out[(size_t)cart_index(l, px, py) * ns + col] += N * C;
+                }
+            }
+    }
+}
+
+extern "C" int mi_c2s_table(int l, double *out)
+{
+    if (l < 0 || l > 6) return fail("mi_c2s_table: l=%d out of range", l);
+    std::vector<double> c;
+    c2s_generic(l, c);
+    memcpy(out, c.data(), c.size() * sizeof(double));
+    return 0;
+}
+
+// =================================================================================================
+// Rys roots and weights from the generated Chebyshev tables (host + device versions)
+// =================================================================================================
+struct RysDev {
+    const double *cheb;   // RYS_CHEB
+    const double *herm_r; // [(NMAX+1)*NMAX]
+    const double *herm_w;
+    int off[RYS_NMAX + 2];
+    int nint[RYS_NMAX + 1];
+};
+
+template <class T>
+__device__ inline double rys_eval_impl(const T &R, int n, int f, double x)
+{
+    int ni = R.nint[n];
+    if (x < ni * RYS_H) {
+        int iv = (int)(x * (1.0 / RYS_H));
+        if (iv >= ni) iv = ni - 1;
+        double s = (x - (iv * RYS_H + 0.5 * RYS_H)) * (2.0 / RYS_H);
+        const double *c = R.cheb + R.off[n] + (size_t)(iv * 2 * n + f) * (RYS_DEG + 1);
+        double b1 = 0.0, b2 = 0.0, s2 = 2.0 * s;
+#pragma unroll
+        for (int k = RYS_DEG; k >= 1; k--) {
+            double t = s2 * b1 - b2 + c[k];
+            b2 = b1;
+            b1 = t;
+        }
+        return s * b1 - b2 + c[0];
+    }
+    if (f < n) return R.herm_r[n * RYS_NMAX + f] / x;
+    return R.herm_w[n * RYS_NMAX + (f - n)] * rsqrt(x);
+}
+__device__ inline double rys_eval(const RysDev &R, int n, int f, double x) { return rys_eval_impl(R, n, f, x); }
+
+extern "C" int mi_rys_roots_host(int n, double x, double *roots, double *weights)
+{
+    if (n < 1 || n > RYS_NMAX) return fail("nroots out of range");
+    struct H { const double *cheb, *herm_r, *herm_w; int off[RYS_NMAX + 2]; int nint[RYS_NMAX + 1]; } R;
+    R.cheb = RYS_CHEB_H; R.herm_r = &RYS_HERM_R_H[0][0]; R.herm_w = &RYS_HERM_W_H[0][0];
+    for (int i = 0; i <= RYS_NMAX; i++) { R.off[i] = i == 0 ? 0 : RYS_OFFSET_H[i]; R.nint[i] = RYS_NINT_H[i]; }
+    for (int f = 0; f < n; f++) {
+        // host path mirrors rys_eval_impl but with std:: functions
+        int ni = R.nint[n];
+        for (int pass = 0; pass < 2; pass++) {
+            int ff = f + pass * n;
+            double val;
+            if (x < ni * RYS_H) {
+                int iv = (int)(x / RYS_H);
+                if (iv >= ni) iv = ni - 1;
+                double s = (x - (iv * RYS_H + 0.5 * RYS_H)) * (2.0 / RYS_H);
+                const double *c = R.cheb + R.off[n] + (size_t)(iv * 2 * n + ff) * (RYS_DEG + 1);
+                double b1 = 0, b2 = 0;
+                for (int k = RYS_DEG; k >= 1; k--) { double t = 2 * s * b1 - b2 + c[k]; b2 = b1; b1 = t; }
+                val = s * b1 - b2 + c[0];
+            } else if (pass == 0) val = R.herm_r[n * RYS_NMAX + f] / x;
+            else val = R.herm_w[n * RYS_NMAX + f] / std::sqrt(x);
+            (pass == 0 ? roots : weights)[f] = val;
+        }
+    }
+    return 0;
+}
+
+// =================================================================================================
+// Context
+// =================================================================================================
+struct ShellH {
+    int atom, l, nprim, ao;
+    const double *exps, *coef;
+    double r[3];
+};
+
+struct PairRec { // one shell pair (l_i >= l_j)
+    int sh_i, sh_j, ao_i, ao_j;
+    int prim_off, nprim; // primitive pairs: 8 doubles each {p,Px,Py,Pz,PAx,PAy,PAz,K}
+    int m_off;           // offset (doubles) of the [ns_i*ns_j][ne] HRR*c2s matrix
+    int pad;
+};
+
+struct PairClass {
+    int la, lb;
+    int ne;                        // number of [e0| cartesian components, e = la..la+lb
+    int nsab;                      // (2la+1)(2lb+1)
+    std::vector<PairRec> recs;     // sorted by q desc after Schwarz
+    std::vector<double> q;         // Schwarz bound per rec
+    PairRec *d_recs = nullptr;
+    double *d_q = nullptr;
+};
+
+struct TileInfo { int I, J, K, L; };
+struct RunRec { int J, K, L, first, count; };
+
+struct mi_ctx {
+    int device = 0;
+    int natm = 0, nbas = 0, nao = 0, nblk = 0, npad = 0;
+    std::vector<int32_t> atm, bas;
+    std::vector<double> env;
+    std::vector<ShellH> shells;
+    // device-side basis for 1e kernel
+    double *d_env = nullptr;
+    int32_t *d_bas = nullptr, *d_atm = nullptr;
+    int *d_shell_ao = nullptr;
+    double *d_c2s = nullptr;             // concatenated c2s tables l=0..LMAX
+    int c2s_off[LMAX + 2];
+    RysDev rys;                          // device pointers inside
+    double *d_rys_cheb = nullptr, *d_herm_r = nullptr, *d_herm_w = nullptr;
+    // pairs
+    PairClass pc[NPC];
+    double *d_prim = nullptr;            // all primitive-pair records
+    double *d_M = nullptr;               // all transformation matrices
+    // component index tables per class quadruple (built lazily)
+    // tiles
+    int64_t n_tiles = 0;
+    std::vector<TileInfo> tiles;
+    std::vector<int64_t> tile_off;
+    std::vector<RunRec> runs;
+    int32_t *d_tile_table = nullptr;     // [nbp(nbp+1)/2] -> local tile index or -1
+    int64_t *d_tile_off = nullptr;
+    int *d_tile_I = nullptr;
+    RunRec *d_runs = nullptr;
+    double *d_tiles = nullptr;
+    int64_t tile_doubles = 0;
+    // J/K work buffers
+    double *d_Dpad = nullptr, *d_Jacc = nullptr, *d_Kacc = nullptr;
+    int ldp = 0;
+    double *d_red = nullptr;
+    mi_eri_stats stats{};
+    bool eri_ready = false;
+};
+
+static inline int pc_index(int la, int lb) { return la * (la + 1) / 2 + lb; }
+static inline int ne_of(int la, int lb) { int n = 0; for (int e = la; e <= la + lb; e++) n += ncart(e); return n; }
+
+static double gaussian_int(int n, double a) { return std::tgamma((n + 1) * 0.5) / (2.0 * std::pow(a, (n + 1) * 0.5)); }
+
+extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, int nbas, const double *env,
+                             int nenv, int device_id, mi_ctx **out)
+{
+    if (!atm || !bas || !env || !out || natm <= 0 || nbas <= 0) return fail("mi_ctx_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("mi_ctx_create: no HIP device available (this engine has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail("mi_ctx_create: device %d out of range (have %d)", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+    mi_ctx *c = new mi_ctx();
+    c->device = device_id;
+    c->natm = natm; c->nbas = nbas;
+    c->atm.assign(atm, atm + (size_t)natm * ATM_SLOTS);
+    c->bas.assign(bas, bas + (size_t)nbas * BAS_SLOTS);
+    c->env.assign(env, env + nenv);
+    int ao = 0;
+    std::vector<int> shell_ao(nbas + 1);
+    for (int i = 0; i < nbas; i++) {
+        const int32_t *b = bas + (size_t)i * BAS_SLOTS;
+        if (b[3] != 1) { delete c; return fail("shell %d: nctr=%d unsupported (split general contractions)", i, b[3]); }
+        if (b[1] < 0 || b[1] > LMAX) { delete c; return fail("shell %d: l=%d unsupported (max %d)", i, b[1], LMAX); }
+        ShellH s;
+        s.atom = b[0]; s.l = b[1]; s.nprim = b[2]; s.ao = ao;
+        s.exps = c->env.data() + b[5]; s.coef = c->env.data() + b[6];
+        const double *r = c->env.data() + atm[(size_t)s.atom * ATM_SLOTS + 1];
+        s.r[0] = r[0]; s.r[1] = r[1]; s.r[2] = r[2];
+        c->shells.push_back(s);
+        shell_ao[i] = ao;
+        ao += 2 * s.l + 1;
+    }
+    shell_ao[nbas] = ao;
+    c->nao = ao;
+    c->nblk = (ao + BLK - 1) / BLK;
+    c->npad = c->nblk * BLK;
+    c->ldp = c->npad + BLK;
+    // device copies
+    HIPCHK(hipMalloc(&c->d_env, sizeof(double) * nenv));
+    HIPCHK(hipMemcpy(c->d_env, env, sizeof(double) * nenv, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_bas, sizeof(int32_t) * nbas * BAS_SLOTS));
+    HIPCHK(hipMemcpy(c->d_bas, bas, sizeof(int32_t) * nbas * BAS_SLOTS, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_atm, sizeof(int32_t) * natm * ATM_SLOTS));
+    HIPCHK(hipMemcpy(c->d_atm, atm, sizeof(int32_t) * natm * ATM_SLOTS, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_shell_ao, sizeof(int) * (nbas + 1)));
+    HIPCHK(hipMemcpy(c->d_shell_ao, shell_ao.data(), sizeof(int) * (nbas + 1), hipMemcpyHostToDevice));
+    // c2s tables
+    std::vector<double> all;
+    for (int l = 0; l <= LMAX; l++) {
+        std::vector<double> t;
+        c2s_generic(l, t);
+        c->c2s_off[l] = (int)all.size();
+        all.insert(all.end(), t.begin(), t.end());
+    }
+    c->c2s_off[LMAX + 1] = (int)all.size();
+    HIPCHK(hipMalloc(&c->d_c2s, sizeof(double) * all.size()));
+    HIPCHK(hipMemcpy(c->d_c2s, all.data(), sizeof(double) * all.size(), hipMemcpyHostToDevice));
+    // Rys tables
+    HIPCHK(hipMalloc(&c->d_rys_cheb, sizeof(double) * RYS_CHEB_SIZE));
+    HIPCHK(hipMemcpy(c->d_rys_cheb, RYS_CHEB_H, sizeof(double) * RYS_CHEB_SIZE, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_herm_r, sizeof(RYS_HERM_R_H)));
+    HIPCHK(hipMemcpy(c->d_herm_r, RYS_HERM_R_H, sizeof(RYS_HERM_R_H), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_herm_w, sizeof(RYS_HERM_W_H)));
+    HIPCHK(hipMemcpy(c->d_herm_w, RYS_HERM_W_H, sizeof(RYS_HERM_W_H), hipMemcpyHostToDevice));
+    c->rys.cheb = c->d_rys_cheb; c->rys.herm_r = c->d_herm_r; c->rys.herm_w = c->d_herm_w;
+    for (int i = 0; i <= RYS_NMAX + 1; i++) c->rys.off[i] = RYS_OFFSET_H[i];
+    for (int i = 0; i <= RYS_NMAX; i++) c->rys.nint[i] = RYS_NINT_H[i];
+    // shift: RYS_OFFSET_H[n] is the offset of block n (n>=1) -- see generator: offs[0]=0 is block 1.
+    for (int n = 1; n <= RYS_NMAX; n++) c->rys.off[n] = RYS_OFFSET_H[n];
+    // J/K buffers
+    size_t pp = (size_t)c->ldp * c->ldp;
+    HIPCHK(hipMalloc(&c->d_Dpad, sizeof(double) * pp));
+    HIPCHK(hipMalloc(&c->d_Jacc, sizeof(double) * pp));
+    HIPCHK(hipMalloc(&c->d_Kacc, sizeof(double) * pp));
+    HIPCHK(hipMalloc(&c->d_red, sizeof(double) * 4096));
+    *out = c;
+    return 0;
+}
+
+static void free_eri(mi_ctx *c)
+{
+    for (int i = 0; i < NPC; i++) {
+        if (c->pc[i].d_recs) hipFree(c->pc[i].d_recs);
+        if (c->pc[i].d_q) hipFree(c->pc[i].d_q);
+        c->pc[i].d_recs = nullptr; c->pc[i].d_q = nullptr;
+        c->pc[i].recs.clear(); c->pc[i].q.clear();
+    }
+    void *ptrs[] = {c->d_prim, c->d_M, c->d_tile_table, c->d_tile_off, c->d_tile_I, c->d_runs, c->d_tiles};
+    for (void *p : ptrs) if (p) hipFree(p);
+    c->d_prim = c->d_M = nullptr; c->d_tile_table = nullptr; c->d_tile_off = nullptr; c->d_tile_I = nullptr;
+    c->d_runs = nullptr; c->d_tiles = nullptr;
+    c->eri_ready = false;
+}
+
+extern "C" void mi_ctx_destroy(mi_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    free_eri(c);
+    void *ptrs[] = {c->d_env, c->d_bas, c->d_atm, c->d_shell_ao, c->d_c2s, c->d_rys_cheb, c->d_herm_r, c->d_herm_w,
+                    c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete c;
+}
+
+extern "C" int mi_ctx_nao(const mi_ctx *c) { return c ? c->nao : -1; }
+
+// =================================================================================================
+// One-electron integrals: one thread per shell pair (i >= j)
+// =================================================================================================
+#define NC1 10 /* ncart(LMAX) */
+
+__device__ inline void cart_pow(int l, int idx, int &x, int &y, int &z)
+{
+    int n = 0;
+    for (int lx = l; lx >= 0; lx--) {
+        int cnt = l - lx + 1;
+        if (idx < n + cnt) { x = lx; y = l - lx - (idx - n); z = l - x - y; return; }
+        n += cnt;
+    }
+    x = y = z = 0;
+}
+
+struct Int1eArgs {
+    const int32_t *atm, *bas;
+    const double *env;
+    const int *shell_ao;
+    const double *c2s;
+    int c2s_off[LMAX + 2];
+    RysDev rys;
+    int natm, nbas, nao;
+    double *S, *T, *V, *dip;
+    double org[3];
+};
+
+__global__ __launch_bounds__(64) void int1e_kernel(Int1eArgs A)
+{
+    int pid = blockIdx.x * blockDim.x + threadIdx.x;
+    int npair = A.nbas * (A.nbas + 1) / 2;
+    if (pid >= npair) return;
+    int ish = (int)((sqrt(8.0 * pid + 1.0) - 1.0) * 0.5);
+    while ((ish + 1) * (ish + 2) / 2 <= pid) ish++;
+    while (ish * (ish + 1) / 2 > pid) ish--;
+    int jsh = pid - ish * (ish + 1) / 2;
+    const int32_t *bi = A.bas + ish * BAS_SLOTS, *bj = A.bas + jsh * BAS_SLOTS;
+    int la = bi[1], lb = bj[1];
+    const double *ra = A.env + A.atm[bi[0] * ATM_SLOTS + 1], *rb = A.env + A.atm[bj[0] * ATM_SLOTS + 1];
+    int nca = (la + 1) * (la + 2) / 2, ncb = (lb + 1) * (lb + 2) / 2;
+    // 6 cartesian blocks: S, T, V, x, y, z
+    double blk[6][NC1 * NC1];
+    for (int m = 0; m < 6; m++)
+        for (int k = 0; k < nca * ncb; k++) blk[m][k] = 0.0;
+    double AB[3] = {ra[0] - rb[0], ra[1] - rb[1], ra[2] - rb[2]};
+    for (int ip = 0; ip < bi[2]; ip++)
+        for (int jp = 0; jp < bj[2]; jp++) {
+            double a = A.env[bi[5] + ip], b = A.env[bj[5] + jp];
+            double cc = A.env[bi[6] + ip] * A.env[bj[6] + jp];
+            double p = a + b, mu = a * b / p, h = 0.5 / p;
+            double ex = exp(-mu * (AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2]));
+            double P[3], PA[3], PB[3];
+            for (int d = 0; d < 3; d++) { P[d] = (a * ra[d] + b * rb[d]) / p; PA[d] = P[d] - ra[d]; PB[d] = P[d] - rb[d]; }
+            // 1-D overlaps s[d][i][j], i <= la+1, j <= lb+2
+            double s[3][LMAX + 2][LMAX + 3];
+            for (int d = 0; d < 3; d++) {
+                s[d][0][0] = 1.0;
+                for (int i = 0; i <= la; i++)
+                    s[d][i + 1][0] = PA[d] * s[d][i][0] + (i > 0 ? i * h * s[d][i - 1][0] : 0.0);
+                for (int j = 0; j <= lb + 1; j++)
+                    for (int i = 0; i <= la + 1; i++)
+                        s[d][i][j + 1] = PB[d] * s[d][i][j] + (i > 0 ? i * h * s[d][i - 1][j] : 0.0) + (j > 0 ? j * h * s[d][i][j - 1] : 0.0);
+            }
+            double pref = cc * ex * pow(M_PI / p, 1.5);
+            for (int ia = 0; ia < nca; ia++) {
+                int pa[3];
+                cart_pow(la, ia, pa[0], pa[1], pa[2]);
+                for (int ib = 0; ib < ncb; ib++) {
+                    int pb[3];
+                    cart_pow(lb, ib, pb[0], pb[1], pb[2]);
+                    double s1[3], t1[3], x1[3];
+                    for (int d = 0; d < 3; d++) {
+                        int i = pa[d], j = pb[d];
+                        double sij = s[d][i][j];
+                        double tij = -2.0 * b * (2 * j + 1) * sij + 4.0 * b * b * s[d][i][j + 2];
+                        if (j >= 2) tij += j * (j - 1) * s[d][i][j - 2];
+                        s1[d] = sij; t1[d] = -0.5 * tij;
+                        x1[d] = s[d][i + 1][j] + (ra[d] - A.org[d]) * sij;
+                    }
+                    int k = ia * ncb + ib;
+                    blk[0][k] += pref * s1[0] * s1[1] * s1[2];
+                    blk[1][k] += pref * (t1[0] * s1[1] * s1[2] + s1[0] * t1[1] * s1[2] + s1[0] * s1[1] * t1[2]);
+                    blk[3][k] += pref * x1[0] * s1[1] * s1[2];
+                    blk[4][k] += pref * s1[0] * x1[1] * s1[2];
+                    blk[5][k] += pref * s1[0] * s1[1] * x1[2];
+                }
+            }
+            // nuclear attraction by Rys quadrature, nroots = (la+lb)/2 + 1
+            int nr = (la + lb) / 2 + 1;
+            double pv = cc * ex * 2.0 * M_PI / p;
+            for (int ic = 0; ic < A.natm; ic++) {
+                double Z = A.atm[ic * ATM_SLOTS + 0];
+                if (Z == 0.0) continue;
+                const double *C = A.env + A.atm[ic * ATM_SLOTS + 1];
+                double PC[3] = {P[0] - C[0], P[1] - C[1], P[2] - C[2]};
+                double x = p * (PC[0] * PC[0] + PC[1] * PC[1] + PC[2] * PC[2]);
+                for (int r = 0; r < nr; r++) {
+                    double u = rys_eval(A.rys, nr, r, x), w = rys_eval(A.rys, nr, nr + r, x);
+                    double g[3][2 * LMAX + 1][LMAX + 1]; // g[d][i][j]
+                    double b10 = (1.0 - u) * h;
+                    for (int d = 0; d < 3; d++) {
+                        double c00 = PA[d] - u * PC[d];
+                        g[d][0][0] = 1.0;
+                        for (int i = 0; i < la + lb; i++)
+                            g[d][i + 1][0] = c00 * g[d][i][0] + (i > 0 ? i * b10 * g[d][i - 1][0] : 0.0);
+                        for (int j = 0; j < lb; j++)
+                            for (int i = 0; i <= la + lb - j - 1; i++) g[d][i][j + 1] = g[d][i + 1][j] + AB[d] * g[d][i][j];
+                    }
+                    double f = -Z * pv * w;
+                    for (int ia = 0; ia < nca; ia++) {
+                        int pa[3];
+                        cart_pow(la, ia, pa[0], pa[1], pa[2]);
+                        for (int ib = 0; ib < ncb; ib++) {
+                            int pb[3];
+                            cart_pow(lb, ib, pb[0], pb[1], pb[2]);
+                            blk[2][ia * ncb + ib] += f * g[0][pa[0]][pb[0]] * g[1][pa[1]][pb[1]] * g[2][pa[2]][pb[2]];
+                        }
+                    }
+                }
+            }
+        }
+    // cart -> sph and store both triangles
+    const double *ca = A.c2s + A.c2s_off[la], *cb = A.c2s + A.c2s_off[lb];
+    int nsa = 2 * la + 1, nsb = 2 * lb + 1;
+    int ao_i = A.shell_ao[ish], ao_j = A.shell_ao[jsh];
+    double *outs[6] = {A.S, A.T, A.V, A.dip, A.dip ? A.dip + (size_t)A.nao * A.nao : nullptr,
+                       A.dip ? A.dip + 2 * (size_t)A.nao * A.nao : nullptr};
+    for (int m = 0; m < 6; m++) {
+        if (!outs[m]) continue;
+        for (int i = 0; i < nsa; i++)
+            for (int j = 0; j < nsb; j++) {
+                double v = 0.0;
+                for (int a = 0; a < nca; a++) {
+                    double t = 0.0;
+                    for (int b = 0; b < ncb; b++) t += blk[m][a * ncb + b] * cb[b * nsb + j];
+                    v += ca[a * nsa + i] * t;
+                }
+                outs[m][(size_t)(ao_i + i) * A.nao + ao_j + j] = v;
+                outs[m][(size_t)(ao_j + j) * A.nao + ao_i + i] = v;
+            }
+    }
+}
+
+extern "C" int mi_int1e(mi_ctx *c, double *d_S, double *d_T, double *d_V, double *d_dip, const double *origin, void *stream)
+{
+    if (!c) return fail("mi_int1e: null context");
+    HIPCHK(hipSetDevice(c->device));
+    Int1eArgs A;
+    A.atm = c->d_atm; A.bas = c->d_bas; A.env = c->d_env; A.shell_ao = c->d_shell_ao; A.c2s = c->d_c2s;
+    for (int i = 0; i <= LMAX + 1; i++) A.c2s_off[i] = c->c2s_off[i];
+    A.rys = c->rys; A.natm = c->natm; A.nbas = c->nbas; A.nao = c->nao;
+    A.S = d_S; A.T = d_T; A.V = d_V; A.dip = d_dip;
+    for (int d = 0; d < 3; d++) A.org[d] = origin ? origin[d] : 0.0;
+    int npair = c->nbas * (c->nbas + 1) / 2;
+    hipLaunchKernelGGL(int1e_kernel, dim3((npair + 63) / 64), dim3(64), 0, (hipStream_t)stream, A);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// =================================================================================================
+// ERI generation, kernel 1: contracted [e0|f0] integrals by Rys quadrature.
+//
+// One 64-lane wave per shell quartet.  Per batch of PB primitive quartets:
+//   phase R  lanes <-> (primitive quartet, root-or-weight function): Chebyshev evaluation -> LDS
+//   phase A  lanes <-> (primitive quartet, root, direction): 2-D vertical recurrence table
+//            T[n][m], n <= la+lb, m <= lc+ld  -> LDS
+//   phase C  lanes <-> output components (e,f): sum over slots of Tx*Ty*Tz, accumulators in VGPRs
+// =================================================================================================
+struct EriArgs {
+    const PairRec *bra, *ket;
+    const double *prim;
+    const int64_t *prefix;   // [nbra+1] cumulative task counts
+    int nbra;
+    int64_t t0, ntask;       // this launch covers tasks [t0, t0+ntask)
+    int la, lb, lc, ld;
+    int nmax, mmax, nroots, tsz; // tsz = (nmax+1)*(mmax+1)
+    int ncomp, PB;
+    const uint32_t *comp;    // [ncomp] packed ix | iy<<10 | iz<<20
+    double *work;            // [ntask][ncomp]
+    RysDev rys;
+    int diag;                // 1: Schwarz mode, ket == bra and task b -> (b,b)
+};
+
+__device__ inline void find_task(const int64_t *prefix, int nbra, int64_t t, int &ib, int &ik)
+{
+    int lo = 0, hi = nbra; // find ib with prefix[ib] <= t < prefix[ib+1]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= t) lo = mid; else hi = mid;
+    }
+    ib = lo;
+    ik = (int)(t - prefix[lo]);
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t task = A.t0 + blockIdx.x;
+    int ib, ik;
+    if (A.diag) { ib = (int)task; ik = ib; }
+    else find_task(A.prefix, A.nbra, task, ib, ik);
+    const PairRec ab = A.bra[ib], cd = A.ket[ik];
+    const int n = A.nroots, tsz = A.tsz, M1 = A.mmax + 1;
+    const int ncd = cd.nprim, nPQ = ab.nprim * ncd;
+    const int PB = A.PB;
+    double *T0 = lds;                       // [PB*n][3][tsz]
+    double *rw = lds + (size_t)PB * n * 3 * tsz; // [PB][2n]
+    double *wout = A.work + (size_t)blockIdx.x * A.ncomp;
+
+    for (int c0 = 0; c0 < A.ncomp; c0 += 64 * MAXC) {
+        double acc[MAXC];
+        uint32_t idx[MAXC];
+#pragma unroll
+        for (int ci = 0; ci < MAXC; ci++) {
+            acc[ci] = 0.0;
+            int c = c0 + ci * 64 + lane;
+            idx[ci] = (c < A.ncomp) ? A.comp[c] : 0xFFFFFFFFu;
+        }
+        for (int pq0 = 0; pq0 < nPQ; pq0 += PB) {
+            const int npq = min(PB, nPQ - pq0);
+            // ---- phase R
+            if (lane < npq * 2 * n) {
+                int pql = lane / (2 * n), f = lane - pql * 2 * n;
+                int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
+                const double *b = A.prim + (size_t)(ab.prim_off + ip) * 8, *k = A.prim + (size_t)(cd.prim_off + jp) * 8;
+                double p = b[0], q = k[0];
+                double dx = b[1] - k[1], dy = b[2] - k[2], dz = b[3] - k[3];
+                double x = p * q / (p + q) * (dx * dx + dy * dy + dz * dz);
+                rw[pql * 2 * n + f] = rys_eval(A.rys, n, f, x);
+            }
+            __syncthreads();
+            // ---- phase A
+            if (lane < npq * n * 3) {
+                int pql = lane / (3 * n), rem = lane - pql * 3 * n, r = rem / 3, d = rem - r * 3;
+                int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
+                const double *b = A.prim + (size_t)(ab.prim_off + ip) * 8, *k = A.prim + (size_t)(cd.prim_off + jp) * 8;
+                double p = b[0], q = k[0], pq1 = 1.0 / (p + q);
+                double u = rw[pql * 2 * n + r];
+                double PQd = b[1 + d] - k[1 + d];
+                double b00 = 0.5 * u * pq1;
+                double b10 = 0.5 / p * (1.0 - u * q * pq1);
+                double b01 = 0.5 / q * (1.0 - u * p * pq1);
+                double c00 = b[4 + d] - u * q * pq1 * PQd;
+                double c01 = k[4 + d] + u * p * pq1 * PQd;
+                double *T = T0 + ((size_t)(pql * n + r) * 3 + d) * tsz;
+                double t00 = 1.0;
+                if (d == 2) {
+                    double w = rw[pql * 2 * n + n + r];
+                    t00 = w * b[7] * k[7] * 34.986836655249725 /* 2 pi^2.5 */ * pq1 * sqrt(p + q) / (p * q) ;
+                    // 2 pi^(5/2) / (p q sqrt(p+q)) = 2 pi^2.5 * sqrt(p+q)/(p q (p+q))
+                }
+                T[0] = t00;
+                double tm = 0.0, tc = t00;
+                for (int i = 0; i < A.nmax; i++) {
+                    double tn = c00 * tc + i * b10 * tm;
+                    T[(i + 1) * M1] = tn;
+                    tm = tc; tc = tn;
+                }
+                for (int m = 0; m < A.mmax; m++)
+                    for (int i = 0; i <= A.nmax; i++) {
+                        double v = c01 * T[i * M1 + m];
+                        if (m > 0) v += m * b01 * T[i * M1 + m - 1];
+                        if (i > 0) v += i * b00 * T[(i - 1) * M1 + m];
+                        T[i * M1 + m + 1] = v;
+                    }
+            }
+            __syncthreads();
+            // ---- phase C
+            const int nslot = npq * n;
+            for (int s = 0; s < nslot; s++) {
+                const double *Tx = T0 + (size_t)s * 3 * tsz, *Ty = Tx + tsz, *Tz = Ty + tsz;
+#pragma unroll
+                for (int ci = 0; ci < MAXC; ci++) {
+                    uint32_t w = idx[ci];
+                    if (w != 0xFFFFFFFFu) acc[ci] += Tx[w & 1023u] * Ty[(w >> 10) & 1023u] * Tz[(w >> 20) & 1023u];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ci = 0; ci < MAXC; ci++) {
+            int c = c0 + ci * 64 + lane;
+            if (c < A.ncomp) wout[c] = acc[ci];
+        }
+    }
+}
+
+// =================================================================================================
+// ERI generation, kernel 2: out[ab][cd] = M_ab . E0 . M_cd^T (HRR + cart->sph folded into M), then
+// scatter every symmetry image that lands in a canonical resident tile.  One wave per quartet.
+// Tile element (i,j,k,l) lives at  off + (((j*4 + l/2) * (bi*bk) + i*bk + k) * 2 + (l&1)).
+// =================================================================================================
+struct XfArgs {
+    const PairRec *bra, *ket;
+    const double *Mbuf;
+    const int64_t *prefix;
+    int nbra;
+    int64_t t0;
+    int ne, nf, nsab, nscd, nsb, nsd;
+    const double *work;
+    int ncomp;
+    const int32_t *tile_table;
+    const int64_t *tile_off;
+    double *tiles;
+    int nao;
+};
+
+__device__ inline void put_tile(const XfArgs &A, int i, int j, int k, int l, double v)
+{
+    int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
+    if (I < J || K < L) return;
+    int bij = I * (I + 1) / 2 + J, bkl = K * (K + 1) / 2 + L;
+    if (bij < bkl) return;
+    int32_t t = A.tile_table[(size_t)bij * (bij + 1) / 2 + bkl];
+    if (t < 0) return;
+    double w = v;
+    if (I == J) w *= 0.5;
+    if (K == L) w *= 0.5;
+    if (bij == bkl) w *= 0.5;
+    int bi = min(BLK, A.nao - I * BLK), bk = min(BLK, A.nao - K * BLK);
+    int ii = i & 7, jj = j & 7, kk = k & 7, ll = l & 7;
+    A.tiles[A.tile_off[t] + ((size_t)((jj * 4 + (ll >> 1)) * (bi * bk) + ii * bk + kk) * 2 + (ll & 1))] = w;
+}
+
+__global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    int ib, ik;
+    find_task(A.prefix, A.nbra, A.t0 + blockIdx.x, ib, ik);
+    const PairRec ab = A.bra[ib], cd = A.ket[ik];
+    const double *E0g = A.work + (size_t)blockIdx.x * A.ncomp;
+    double *E0 = lds;                 // [ne][nf]
+    double *X = lds + A.ne * A.nf;    // [nsab][nf]
+    for (int c = lane; c < A.ne * A.nf; c += 64) E0[c] = E0g[c];
+    __syncthreads();
+    const double *Mab = A.Mbuf + ab.m_off, *Mcd = A.Mbuf + cd.m_off;
+    for (int o = lane; o < A.nsab * A.nf; o += 64) {
+        int r = o / A.nf, f = o - r * A.nf;
+        double s = 0.0;
+        for (int e = 0; e < A.ne; e++) s += Mab[r * A.ne + e] * E0[e * A.nf + f];
+        X[o] = s;
+    }
+    __syncthreads();
+    for (int o = lane; o < A.nsab * A.nscd; o += 64) {
+        int r = o / A.nscd, c = o - r * A.nscd;
+        double s = 0.0;
+        for (int f = 0; f < A.nf; f++) s += X[r * A.nf + f] * Mcd[c * A.nf + f];
+        int sa = r / A.nsb, sb = r - sa * A.nsb, sc = c / A.nsd, sd = c - sc * A.nsd;
+        int i = ab.ao_i + sa, j = ab.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
+        put_tile(A, i, j, k, l, s); put_tile(A, j, i, k, l, s); put_tile(A, i, j, l, k, s); put_tile(A, j, i, l, k, s);
+        put_tile(A, k, l, i, j, s); put_tile(A, l, k, i, j, s); put_tile(A, k, l, j, i, s); put_tile(A, l, k, j, i, s);
+    }
+}
+
+// Schwarz: q[b] = sqrt(max_ab |(ab|ab)|) from the diagonal-task E0 blocks.
+struct SchwarzArgs {
+    const PairRec *bra;
+    const double *Mbuf;
+    const double *work;
+    int ne, nsab, ncomp;
+    double *q;
+};
+__global__ __launch_bounds__(64) void schwarz_diag_kernel(SchwarzArgs A)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const PairRec ab = A.bra[blockIdx.x];
+    const double *E0g = A.work + (size_t)blockIdx.x * A.ncomp;
+    for (int c = lane; c < A.ne * A.ne; c += 64) lds[c] = E0g[c];
+    __syncthreads();
+    const double *M = A.Mbuf + ab.m_off;
+    double mx = 0.0;
+    for (int r = lane; r < A.nsab; r += 64) {
+        double s = 0.0;
+        for (int e = 0; e < A.ne; e++) {
+            double t = 0.0;
+            for (int f = 0; f < A.ne; f++) t += lds[e * A.ne + f] * M[r * A.ne + f];
+            s += M[r * A.ne + e] * t;
+        }
+        mx = fmax(mx, fabs(s));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if (lane == 0) A.q[blockIdx.x] = sqrt(mx);
+}
+
+// =================================================================================================
+// Host side of ERI preparation
+// =================================================================================================
+static void build_comp_table(int la, int lb, int lc, int ld, std::vector<uint32_t> &comp)
+{
+    int M1 = lc + ld + 1;
+    comp.clear();
+    for (int e = la; e <= la + lb; e++)
+        for (int ex = e; ex >= 0; ex--)
+            for (int ey = e - ex; ey >= 0; ey--) {
+                int ez = e - ex - ey;
+                for (int f = lc; f <= lc + ld; f++)
+                    for (int fx = f; fx >= 0; fx--)
+                        for (int fy = f - fx; fy >= 0; fy--) {
+                            int fz = f - fx - fy;
+                            uint32_t ix = ex * M1 + fx, iy = ey * M1 + fy, iz = ez * M1 + fz;
+                            comp.push_back(ix | (iy << 10) | (iz << 20));
+                        }
+            }
+}
+
+// M[(sa,sb)][e] = sum_{a,b cart} c2s_a[a][sa] c2s_b[b][sb] prod_d C(b_d,i_d) AB_d^(b_d-i_d), e = a + i
+static void build_M(int la, int lb, const double AB[3], const std::vector<double> &ca, const std::vector<double> &cb,
+                    double *M /* [nsa*nsb][ne] */)
+{
+    int nsa = 2 * la + 1, nsb = 2 * lb + 1, ne = ne_of(la, lb);
+    std::fill(M, M + (size_t)nsa * nsb * ne, 0.0);
+    // e-offsets by degree
+    int eoff[2 * LMAX + 2];
+    eoff[la] = 0;
+    for (int e = la; e < la + lb + 1; e++) eoff[e + 1] = eoff[e] + ncart(e);
+    double pw[3][LMAX + 1];
+    for (int d = 0; d < 3; d++) { pw[d][0] = 1.0; for (int k = 1; k <= LMAX; k++) pw[d][k] = pw[d][k - 1] * AB[d]; }
+    int ia = 0;
+    for (int ax = la; ax >= 0; ax--)
+        for (int ay = la - ax; ay >= 0; ay--, ia++) {
+            int az = la - ax - ay;
+            int ibx = 0;
+            for (int bx = lb; bx >= 0; bx--)
+                for (int by = lb - bx; by >= 0; by--, ibx++) {
+                    int bz = lb - bx - by;
+                    for (int ix = 0; ix <= bx; ix++)
+                        for (int iy = 0; iy <= by; iy++)
+                            for (int iz = 0; iz <= bz; iz++) {
+                                double coef = binom(bx, ix) * binom(by, iy) * binom(bz, iz) * pw[0][bx - ix] * pw[1][by - iy] * pw[2][bz - iz];
+                                int deg = la + ix + iy + iz;
+                                int e = eoff[deg] + cart_index(deg, ax + ix, ay + iy);
+                                for (int sa = 0; sa < nsa; sa++) {
+                                    double c1 = ca[(size_t)ia * nsa + sa];
+                                    if (c1 == 0.0) continue;
+                                    for (int sb = 0; sb < nsb; sb++) {
+                                        double c2 = cb[(size_t)ibx * nsb + sb];
+                                        if (c2 != 0.0) M[(size_t)(sa * nsb + sb) * ne + e] += c1 * c2 * coef;
+                                    }
+                                }
+                            }
+                }
+        }
+}
+
+template <class T>
+static int upload(T **dst, const std::vector<T> &v)
+{
+    if (*dst) { hipFree(*dst); *dst = nullptr; }
+    size_t n = std::max<size_t>(v.size(), 1);
+    HIPCHK(hipMalloc((void **)dst, sizeof(T) * n));
+    if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int launch_eri(mi_ctx *c, EriArgs &E, int nblocks, hipStream_t st)
+{
+    size_t shm = sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots);
+    int perlane = (E.ncomp + 63) / 64;
+    if (perlane <= 1) hipLaunchKernelGGL(eri_rys_kernel<1>, dim3(nblocks), dim3(64), shm, st, E);
+    else if (perlane <= 4) hipLaunchKernelGGL(eri_rys_kernel<4>, dim3(nblocks), dim3(64), shm, st, E);
+    else if (perlane <= 16) hipLaunchKernelGGL(eri_rys_kernel<16>, dim3(nblocks), dim3(64), shm, st, E);
+    else hipLaunchKernelGGL(eri_rys_kernel<32>, dim3(nblocks), dim3(64), shm, st, E);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static void setup_eri_dims(EriArgs &E, int la, int lb, int lc, int ld)
+{
+    E.la = la; E.lb = lb; E.lc = lc; E.ld = ld;
+    E.nmax = la + lb; E.mmax = lc + ld;
+    E.nroots = (la + lb + lc + ld) / 2 + 1;
+    E.tsz = (E.nmax + 1) * (E.mmax + 1);
+    E.ncomp = ne_of(la, lb) * ne_of(lc, ld);
+    int pb = 64 / (3 * E.nroots);
+    E.PB = std::max(1, pb);
+}
+
+extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void *stream)
+{
+    if (!c) return fail("mi_eri_prepare: null context");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("mi_eri_prepare: bad rank/nranks");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    auto t_start = std::chrono::steady_clock::now();
+    free_eri(c);
+    const int nbas = c->nbas;
+    std::vector<std::vector<double>> c2s(LMAX + 1);
+    for (int l = 0; l <= LMAX; l++) c2s_generic(l, c2s[l]);
+
+    // ---- 1. shell pairs, primitive-pair records, transformation matrices
+    std::vector<double> prim, Mbuf;
+    for (int la = 0; la <= LMAX; la++)
+        for (int lb = 0; lb <= la; lb++) {
+            PairClass &P = c->pc[pc_index(la, lb)];
+            P.la = la; P.lb = lb; P.ne = ne_of(la, lb); P.nsab = (2 * la + 1) * (2 * lb + 1);
+        }
+    for (int A = 0; A < nbas; A++)
+        for (int B = 0; B <= A; B++) {
+            int si = A, sj = B;
+            if (c->shells[si].l < c->shells[sj].l) std::swap(si, sj);
+            const ShellH &I = c->shells[si], &J = c->shells[sj];
+            PairClass &P = c->pc[pc_index(I.l, J.l)];
+            double AB[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+            double r2 = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
+            PairRec R;
+            R.sh_i = si; R.sh_j = sj; R.ao_i = I.ao; R.ao_j = J.ao; R.pad = 0;
+            R.prim_off = (int)(prim.size() / 8);
+            int np = 0;
+            for (int ip = 0; ip < I.nprim; ip++)
+                for (int jp = 0; jp < J.nprim; jp++) {
+                    double a = I.exps[ip], b = J.exps[jp], p = a + b, mu = a * b / p;
+                    if (mu * r2 > 80.0) continue; // exp(-80) = 1.8e-35: below double resolution of any sum
+                    double K = I.coef[ip] * J.coef[jp] * std::exp(-mu * r2);
+                    double Pc[3];
+                    for (int d = 0; d < 3; d++) Pc[d] = (a * I.r[d] + b * J.r[d]) / p;
+                    double rec[8] = {p, Pc[0], Pc[1], Pc[2], Pc[0] - I.r[0], Pc[1] - I.r[1], Pc[2] - I.r[2], K};
+                    prim.insert(prim.end(), rec, rec + 8);
+                    np++;
+                }
+            if (np == 0) continue;
+            R.nprim = np;
+            R.m_off = (int)Mbuf.size();
+            Mbuf.resize(Mbuf.size() + (size_t)P.nsab * P.ne);
+            build_M(I.l, J.l, AB, c2s[I.l], c2s[J.l], Mbuf.data() + R.m_off);
+            P.recs.push_back(R);
+        }
+    if (Mbuf.size() > (size_t)INT32_MAX) return fail("transformation-matrix buffer exceeds 2^31 doubles");
+    if (upload(&c->d_prim, prim)) return -1;
+    if (upload(&c->d_M, Mbuf)) return -1;
+
+    // workspace for cartesian intermediates
+    const size_t WORK_DOUBLES = (size_t)32 << 20; // 256 MiB
+    double *d_work = nullptr;
+    HIPCHK(hipMalloc(&d_work, sizeof(double) * WORK_DOUBLES));
+    uint32_t *d_comp = nullptr;
+    HIPCHK(hipMalloc(&d_comp, sizeof(uint32_t) * 8192));
+
+    // ---- 2. Schwarz bounds per pair (GPU)
+    double qmax = 0.0;
+    for (int ci = 0; ci < NPC; ci++) {
+        PairClass &P = c->pc[ci];
+        if (P.recs.empty()) continue;
+        if (upload(&P.d_recs, P.recs)) return -1;
+        P.q.assign(P.recs.size(), 0.0);
+        HIPCHK(hipMalloc(&P.d_q, sizeof(double) * P.recs.size()));
+        EriArgs E{};
+        setup_eri_dims(E, P.la, P.lb, P.la, P.lb);
+        std::vector<uint32_t> comp;
+        build_comp_table(P.la, P.lb, P.la, P.lb, comp);
+        HIPCHK(hipMemcpyAsync(d_comp, comp.data(), sizeof(uint32_t) * comp.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        E.bra = E.ket = P.d_recs; E.prim = c->d_prim; E.prefix = nullptr; E.nbra = (int)P.recs.size();
+        E.comp = d_comp; E.work = d_work; E.rys = c->rys; E.diag = 1;
+        size_t per = WORK_DOUBLES / E.ncomp;
+        for (size_t b0 = 0; b0 < P.recs.size(); b0 += per) {
+            int nb = (int)std::min(per, P.recs.size() - b0);
+            E.t0 = (int64_t)b0; E.ntask = nb;
+            if (launch_eri(c, E, nb, st)) return -1;
+            SchwarzArgs S{P.d_recs + b0, c->d_M, d_work, P.ne, P.nsab, E.ncomp, P.d_q + b0};
+            hipLaunchKernelGGL(schwarz_diag_kernel, dim3(nb), dim3(64), sizeof(double) * P.ne * P.ne, st, S);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(P.q.data(), P.d_q, sizeof(double) * P.q.size(), hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (int ci = 0; ci < NPC; ci++)
+        for (double v : c->pc[ci].q) qmax = std::max(qmax, v);
+
+    // ---- 3. sort pairs by q (descending), drop negligible ones; block-pair Schwarz bounds
+    const int nblk = c->nblk;
+    const int nbp = nblk * (nblk + 1) / 2;
+    std::vector<double> Qblk(nbp, 0.0);
+    for (int ci = 0; ci < NPC; ci++) {
+        PairClass &P = c->pc[ci];
+        std::vector<int> ord(P.recs.size());
+        std::iota(ord.begin(), ord.end(), 0);
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return P.q[a] > P.q[b]; });
+        std::vector<PairRec> r2;
+        std::vector<double> q2;
+        for (int o : ord) {
+            if (P.q[o] * qmax < tol) break;
+            r2.push_back(P.recs[o]);
+            q2.push_back(P.q[o]);
+            const PairRec &R = P.recs[o];
+            int ni = 2 * P.la + 1, nj = 2 * P.lb + 1;
+            for (int I = R.ao_i / BLK; I <= (R.ao_i + ni - 1) / BLK; I++)
+                for (int J = R.ao_j / BLK; J <= (R.ao_j + nj - 1) / BLK; J++) {
+                    int hi = std::max(I, J), lo = std::min(I, J);
+                    double &Q = Qblk[hi * (hi + 1) / 2 + lo];
+                    Q = std::max(Q, P.q[o]);
+                }
+        }
+        P.recs.swap(r2);
+        P.q.swap(q2);
+        if (upload(&P.d_recs, P.recs)) return -1;
+    }
+
+    // ---- 4. tiles and runs.  Run = tiles sharing (J,K,L), ordered by I; long runs are split.
+    const int RUNMAX = 8;
+    std::vector<int> bpI(nbp), bpJ(nbp);
+    for (int I = 0, n = 0; I < nblk; I++)
+        for (int J = 0; J <= I; J++, n++) { bpI[n] = I; bpJ[n] = J; }
+    auto bsize = [&](int B) { return std::min(BLK, c->nao - B * BLK); };
+    c->tiles.clear(); c->tile_off.clear(); c->runs.clear();
+    std::vector<int32_t> table((size_t)nbp * (nbp + 1) / 2, -1);
+    int64_t off = 0, nuniq = 0;
+    int64_t run_counter = 0;
+    for (int kl = 0; kl < nbp; kl++) {
+        int K = bpI[kl], L = bpJ[kl];
+        if (Qblk[kl] * qmax < tol) continue;
+        for (int J = 0; J < nblk; J++) {
+            RunRec cur{J, K, L, 0, 0};
+            bool mine = false;
+            for (int I = J; I < nblk; I++) {
+                int ij = I * (I + 1) / 2 + J;
+                if (ij < kl) continue;
+                if (Qblk[ij] * Qblk[kl] < tol) continue;
+                if (cur.count == 0) {
+                    mine = (run_counter % nranks) == rank;
+                    run_counter++;
+                    cur.first = (int)c->tiles.size();
+                }
+                if (mine) {
+                    table[(size_t)ij * (ij + 1) / 2 + kl] = (int32_t)c->tiles.size();
+                    c->tiles.push_back({I, J, K, L});
+                    c->tile_off.push_back(off);
+                    int bi = bsize(I), bj = bsize(J), bk = bsize(K), bl = bsize(L);
+                    off += (int64_t)bj * 4 * bi * bk * 2;
+                    int64_t nij = (I > J) ? (int64_t)bi * bj : (int64_t)bi * (bi + 1) / 2;
+                    int64_t nkl = (K > L) ? (int64_t)bk * bl : (int64_t)bk * (bk + 1) / 2;
+                    nuniq += (ij > kl) ? nij * nkl : nij * (nij + 1) / 2;
+                }
+                cur.count++;
+                if (cur.count == RUNMAX) {
+                    if (mine) c->runs.push_back(cur);
+                    cur.count = 0;
+                }
+            }
+            if (cur.count > 0 && mine) c->runs.push_back(cur);
+        }
+    }
+    c->n_tiles = (int64_t)c->tiles.size();
+    c->tile_doubles = off;
+    if (c->n_tiles >= INT32_MAX) return fail("too many tiles");
+    if (upload(&c->d_tile_table, table)) return -1;
+    if (upload(&c->d_tile_off, c->tile_off)) return -1;
+    {
+        std::vector<int> tI(c->tiles.size());
+        for (size_t i = 0; i < tI.size(); i++) tI[i] = c->tiles[i].I;
+        if (upload(&c->d_tile_I, tI)) return -1;
+        if (upload(&c->d_runs, c->runs)) return -1;
+    }
+    size_t freeb = 0, totb = 0;
+    HIPCHK(hipMemGetInfo(&freeb, &totb));
+    if ((size_t)off * 8 + ((size_t)1 << 30) > freeb) {
+        hipFree(d_work); hipFree(d_comp);
+        return fail("resident ERI store needs %.1f GB but only %.1f GB of HBM is free; shard over more GPUs",
+                    off * 8e-9, freeb * 1e-9);
+    }
+    HIPCHK(hipMalloc(&c->d_tiles, sizeof(double) * std::max<int64_t>(off, 1)));
+    HIPCHK(hipMemsetAsync(c->d_tiles, 0, sizeof(double) * std::max<int64_t>(off, 1), st));
+
+    // ---- 5. evaluate every Schwarz-surviving canonical shell quartet, class by class
+    int64_t nquart = 0;
+    int64_t *d_prefix = nullptr;
+    size_t prefix_cap = 0;
+    for (int bc = 0; bc < NPC; bc++)
+        for (int kc = 0; kc <= bc; kc++) {
+            PairClass &B = c->pc[bc], &Kc = c->pc[kc];
+            if (B.recs.empty() || Kc.recs.empty()) continue;
+            std::vector<int64_t> prefix(B.recs.size() + 1, 0);
+            for (size_t b = 0; b < B.recs.size(); b++) {
+                double thr = tol / B.q[b];
+                // kets sorted descending: count q >= thr
+                size_t lo = 0, hi = Kc.q.size();
+                while (lo < hi) { size_t mid = (lo + hi) / 2; if (Kc.q[mid] >= thr) lo = mid + 1; else hi = mid; }
+                int64_t cnt = (int64_t)lo;
+                if (bc == kc) cnt = std::min<int64_t>(cnt, (int64_t)b + 1);
+                prefix[b + 1] = prefix[b] + cnt;
+            }
+            int64_t ntask = prefix.back();
+            if (ntask == 0) continue;
+            nquart += ntask;
+            if (prefix.size() > prefix_cap) {
+                if (d_prefix) hipFree(d_prefix);
+                prefix_cap = prefix.size() * 2;
+                HIPCHK(hipMalloc(&d_prefix, sizeof(int64_t) * prefix_cap));
+            }
+            HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
+            EriArgs E{};
+            setup_eri_dims(E, B.la, B.lb, Kc.la, Kc.lb);
+            std::vector<uint32_t> comp;
+            build_comp_table(B.la, B.lb, Kc.la, Kc.lb, comp);
+            HIPCHK(hipMemcpyAsync(d_comp, comp.data(), sizeof(uint32_t) * comp.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st)); // host vectors go out of scope below
+            E.bra = B.d_recs; E.ket = Kc.d_recs; E.prim = c->d_prim; E.prefix = d_prefix; E.nbra = (int)B.recs.size();
+            E.comp = d_comp; E.work = d_work; E.rys = c->rys; E.diag = 0;
+            XfArgs X{};
+            X.bra = B.d_recs; X.ket = Kc.d_recs; X.Mbuf = c->d_M; X.prefix = d_prefix; X.nbra = E.nbra;
+            X.ne = B.ne; X.nf = Kc.ne; X.nsab = B.nsab; X.nscd = Kc.nsab; X.nsb = 2 * B.lb + 1; X.nsd = 2 * Kc.lb + 1;
+            X.work = d_work; X.ncomp = E.ncomp; X.tile_table = c->d_tile_table; X.tile_off = c->d_tile_off;
+            X.tiles = c->d_tiles; X.nao = c->nao;
+            int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
+            size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
+            for (int64_t t0 = 0; t0 < ntask; t0 += per) {
+                int nb = (int)std::min<int64_t>(per, ntask - t0);
+                E.t0 = t0; E.ntask = nb; X.t0 = t0;
+                if (launch_eri(c, E, nb, st)) return -1;
+                hipLaunchKernelGGL(eri_transform_scatter, dim3(nb), dim3(64), shm2, st, X);
+                HIPCHK(hipGetLastError());
+            }
+        }
+    HIPCHK(hipStreamSynchronize(st));
+    if (d_prefix) hipFree(d_prefix);
+    hipFree(d_work);
+    hipFree(d_comp);
+    c->stats.n_tiles = c->n_tiles;
+    c->stats.n_runs = (int64_t)c->runs.size();
+    c->stats.stored_bytes = off * 8;
+    c->stats.n_unique_eri = nuniq;
+    c->stats.n_quartets = nquart;
+    c->stats.seconds_eri = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    c->eri_ready = true;
+    return 0;
+}
+
+extern "C" int mi_eri_get_stats(const mi_ctx *c, mi_eri_stats *out)
+{
+    if (!c || !out) return fail("mi_eri_get_stats: null argument");
+    *out = c->stats;
+    return 0;
+}
+
+// =================================================================================================
+// J/K digestion of the resident tiles.
+//
+// One wave per run (tiles sharing J,K,L; I varies).  Lane (i,k) = (lane>>3, lane&7) owns the 8x8
+// (j,l) sub-block T[i,:,k,:] of each tile and performs all six contractions per loaded value:
+//   per tile  : K_IK (in-lane), J_IJ and K_IL (reduce over the 8 k-lanes)
+//   per run   : J_KL and K_JK (reduce over the 8 i-lanes), K_JL (reduce over all 64 lanes)
+// Partial blocks are added with FP64 global atomics into padded accumulators; the finalize kernel
+// forms J = 2 (Jacc + Jacc^T), K = Kacc + Kacc^T (tile values are pre-weighted, see put_tile).
+// =================================================================================================
+struct JkArgs {
+    const double *tiles;
+    const int64_t *tile_off;
+    const int *tile_I;
+    const RunRec *runs;
+    int nruns;
+    const double *D; // padded [ldp][ldp]
+    double *Jacc, *Kacc;
+    int ld, nao;
+};
+
+__device__ inline double red_select_xor(double a, double b, bool hi, int mask)
+{
+    // keep = hi ? b : a ; send = hi ? a : b ; returns keep + partner's send
+    double keep = hi ? b : a, send = hi ? a : b;
+    return keep + __shfl_xor(send, mask);
+}
+
+// reduce-scatter 8 values over the 3 lane bits {m2, m1, m0}; afterwards the lane holds element
+// ((lane&m2)?4:0)+((lane&m1)?2:0)+((lane&m0)?1:0)
+__device__ inline double reduce8(const double v[8], int lane, int m2, int m1, int m0)
+{
+    double a[4], b[2];
+    bool h2 = lane & m2, h1 = lane & m1, h0 = lane & m0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) a[t] = red_select_xor(v[t], v[t + 4], h2, m2);
+#pragma unroll
+    for (int t = 0; t < 2; t++) b[t] = red_select_xor(a[t], a[t + 2], h1, m1);
+    return red_select_xor(b[0], b[1], h0, m0);
+}
+
+template <bool WITH_J, bool WITH_K>
+__global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
+{
+    const int lane = threadIdx.x;
+    const int run_id = blockIdx.x;
+    if (run_id >= A.nruns) return;
+    const RunRec R = A.runs[run_id];
+    const int i = lane >> 3, k = lane & 7;
+    const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
+    const int ld = A.ld;
+    const int bj = min(BLK, A.nao - J0), bk = min(BLK, A.nao - K0);
+    const double *__restrict__ D = A.D;
+
+    // run-invariant density rows
+    double dKL[8], dJK[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) dKL[l] = D[(size_t)(K0 + k) * ld + L0 + l];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dJK[j] = D[(size_t)(J0 + j) * ld + K0 + k];
+    double kjl[8][8], jkl[8], kjk[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        jkl[j] = 0.0; kjk[j] = 0.0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) kjl[j][l] = 0.0;
+    }
+
+    for (int t = 0; t < R.count; t++) {
+        const int tid = R.first + t;
+        const int I0 = A.tile_I[tid] * BLK;
+        const int bi = min(BLK, A.nao - I0);
+        const bool active = (i < bi) && (k < bk);
+        const double2 *__restrict__ T = reinterpret_cast<const double2 *>(A.tiles + A.tile_off[tid]) + (i * bk + k);
+        const int cs = bi * bk; // double2 stride between (j,lp) chunks
+        double dIJ[8], dIL[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) dIJ[j] = D[(size_t)(I0 + i) * ld + J0 + j];
+#pragma unroll
+        for (int l = 0; l < 8; l++) dIL[l] = D[(size_t)(I0 + i) * ld + L0 + l];
+        const double dIK = D[(size_t)(I0 + i) * ld + K0 + k];
+        double kik = 0.0, jij[8], kil[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { jij[j] = 0.0; kil[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j < bj) {
+                double v[8];
+#pragma unroll
+                for (int lp = 0; lp < 4; lp++) {
+                    double2 x = active ? T[(size_t)(j * 4 + lp) * cs] : make_double2(0.0, 0.0);
+                    v[2 * lp] = x.x; v[2 * lp + 1] = x.y;
+                }
+                const double *__restrict__ dJL = D + (size_t)(J0 + j) * ld + L0; // wave-uniform row
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    const double x = v[l];
+                    if (WITH_K) {
+                        kik = fma(x, dJL[l], kik);
+                        kil[l] = fma(x, dJK[j], kil[l]);
+                        kjl[j][l] = fma(x, dIK, kjl[j][l]);
+                        kjk[j] = fma(x, dIL[l], kjk[j]);
+                    }
+                    if (WITH_J) {
+                        jij[j] = fma(x, dKL[l], jij[j]);
+                        jkl[l] = fma(x, dIJ[j], jkl[l]);
+                    }
+                }
+            }
+        }
+        // per-tile outputs
+        if (WITH_K) {
+            atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik);
+            double r = reduce8(kil, lane, 4, 2, 1); // lane holds l = k
+            atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + L0 + k], r);
+        }
+        if (WITH_J) {
+            double r = reduce8(jij, lane, 4, 2, 1); // lane holds j = k
+            atomicAdd(&A.Jacc[(size_t)(I0 + i) * ld + J0 + k], r);
+        }
+    }
+    // per-run outputs
+    if (WITH_J) {
+        double r = reduce8(jkl, lane, 32, 16, 8); // lane holds l = i
+        atomicAdd(&A.Jacc[(size_t)(K0 + k) * ld + L0 + i], r);
+    }
+    if (WITH_K) {
+        double r = reduce8(kjk, lane, 32, 16, 8); // lane holds j = i
+        atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + K0 + k], r);
+        // K_JL: 64 values over 64 lanes; first over i-lanes for each l-row... do it as 8 x reduce8 then reduce8
+        double s[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            double col[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) col[j] = kjl[j][l];
+            s[l] = reduce8(col, lane, 32, 16, 8); // lane holds j = i, summed over i-lanes, for this l
+        }
+        double r2 = reduce8(s, lane, 4, 2, 1); // lane holds l = k, summed over k-lanes
+        atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + L0 + k], r2);
+    }
+}
+
+__global__ void pad_density_kernel(const double *D, double *Dp, int nao, int ld)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ld * ld) return;
+    int r = idx / ld, c = idx - r * ld;
+    Dp[idx] = (r < nao && c < nao) ? D[(size_t)r * nao + c] : 0.0;
+}
+
+__global__ void finalize_jk_kernel(const double *Jacc, const double *Kacc, double *J, double *K, int nao, int ld)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nao * nao) return;
+    int r = idx / nao, c = idx - r * nao;
+    if (J) J[idx] = 2.0 * (Jacc[(size_t)r * ld + c] + Jacc[(size_t)c * ld + r]);
+    if (K) K[idx] = Kacc[(size_t)r * ld + c] + Kacc[(size_t)c * ld + r];
+}
+
+static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
+{
+    JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_runs, (int)c->runs.size(), c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao};
+    if (A.nruns == 0) return 0;
+    dim3 g(A.nruns), b(64);
+    if (wj && wk) hipLaunchKernelGGL((jk_tiles_kernel<true, true>), g, b, 0, st, A);
+    else if (wj) hipLaunchKernelGGL((jk_tiles_kernel<true, false>), g, b, 0, st, A);
+    else hipLaunchKernelGGL((jk_tiles_kernel<false, true>), g, b, 0, st, A);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_build_jk(mi_ctx *c, const double *d_D, int n_dm, double *d_J, double *d_K, void *stream)
+{
+    if (!c || !d_D) return fail("mi_build_jk: null argument");
+    if (!c->eri_ready) return fail("mi_build_jk: call mi_eri_prepare first");
+    if (!d_J && !d_K) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    size_t nn = (size_t)c->nao * c->nao, pp = (size_t)c->ldp * c->ldp;
+    for (int m = 0; m < n_dm; m++) {
+        hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D + m * nn, c->d_Dpad, c->nao, c->ldp);
+        if (d_J) HIPCHK(hipMemsetAsync(c->d_Jacc, 0, sizeof(double) * pp, st));
+        if (d_K) HIPCHK(hipMemsetAsync(c->d_Kacc, 0, sizeof(double) * pp, st));
+        if (launch_jk(c, d_J != nullptr, d_K != nullptr, st)) return -1;
+        hipLaunchKernelGGL(finalize_jk_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, c->d_Jacc, c->d_Kacc,
+                           d_J ? d_J + m * nn : nullptr, d_K ? d_K + m * nn : nullptr, c->nao, c->ldp);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int mi_time_jk_kernel(mi_ctx *c, const double *d_D, int reps, double *ms, void *stream)
+{
+    if (!c || !d_D || !ms || reps < 1) return fail("mi_time_jk_kernel: bad argument");
+    if (!c->eri_ready) return fail("mi_time_jk_kernel: call mi_eri_prepare first");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    size_t pp = (size_t)c->ldp * c->ldp;
+    hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->nao, c->ldp);
+    HIPCHK(hipMemsetAsync(c->d_Jacc, 0, sizeof(double) * pp, st));
+    HIPCHK(hipMemsetAsync(c->d_Kacc, 0, sizeof(double) * pp, st));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    if (launch_jk(c, true, true, st)) return -1; // warm
+    HIPCHK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; r++)
+        if (launch_jk(c, true, true, st)) return -1;
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    *ms = (double)t / reps;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 0;
+}
+
+// =================================================================================================
+// DIIS helpers
+// =================================================================================================
+__global__ void diis_errvec_kernel(const double *sdf, double *err, int n)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    int r = idx / n, c = idx - r * n;
+    err[idx] = sdf[(size_t)c * n + r] - sdf[idx];
+}
+
+extern "C" int mi_diis_errvec(mi_ctx *c, const double *d_SDF, double *d_err, void *stream)
+{
+    if (!c) return fail("null context");
+    int n = c->nao;
+    hipLaunchKernelGGL(diis_errvec_kernel, dim3((n * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_SDF, d_err, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+struct CoefPack { double c[16]; };
+__global__ void diis_combine_kernel(const double *hist, CoefPack cf, int n, size_t nn, double *out)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nn) return;
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s = fma(cf.c[i], hist[(size_t)i * nn + idx], s);
+    out[idx] = s;
+}
+
+extern "C" int mi_diis_combine(mi_ctx *c, const double *d_hist, const double *coef, int n, double *d_out, void *stream)
+{
+    if (!c || n < 1 || n > 16) return fail("mi_diis_combine: bad argument");
+    CoefPack cf{};
+    for (int i = 0; i < n; i++) cf.c[i] = coef[i];
+    size_t nn = (size_t)c->nao * c->nao;
+    hipLaunchKernelGGL(diis_combine_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_hist, cf, n, nn, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void diis_dots_kernel(const double *hist, const double *e, size_t nn, double *out)
+{
+    __shared__ double sh[4];
+    const double *h = hist + (size_t)blockIdx.x * nn;
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < nn; i += 256) s = fma(h[i], e[i], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+extern "C" int mi_diis_dots(mi_ctx *c, const double *d_hist_e, const double *d_e, int n, double *out, void *stream)
+{
+    if (!c || n < 1 || n > 64) return fail("mi_diis_dots: bad argument");
+    size_t nn = (size_t)c->nao * c->nao;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(diis_dots_kernel, dim3(n), dim3(256), 0, st, d_hist_e, d_e, nn, c->d_red);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}

@@ -1,0 +1,214 @@
+"""ctypes binding of the gfx950 engine library (`include/mi355scf.h`) on PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: it owns device memory for the N x N matrices, the current HIP stream and
+(in `parallel.py`) the RCCL process group.  All hot-path arithmetic happens inside
+`libmi355scf.so`.  There is NO CPU fallback: if the library or a GPU is missing this module raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch  # must be imported before the engine library so both share one HIP runtime (libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
+LIB_PATH = os.path.join(_CSRC, "libmi355scf.so")
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class _Stats(ctypes.Structure):
+    _fields_ = [("n_tiles", ctypes.c_int64), ("n_runs", ctypes.c_int64), ("stored_bytes", ctypes.c_int64),
+                ("n_unique_eri", ctypes.c_int64), ("n_quartets", ctypes.c_int64), ("seconds_eri", ctypes.c_double)]
+
+
+def build_library(force=False):
+    """Compile csrc/ for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    src = os.path.join(_CSRC, "mi355scf.hip")
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(os.path.join(_CSRC, f)) > os.path.getmtime(LIB_PATH)
+        for f in ("mi355scf.hip", "rys_tables.h", "Makefile") if os.path.exists(os.path.join(_CSRC, f)))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(this engine has no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.mi_last_error.restype = ctypes.c_char_p
+        vp, ip, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)
+        L.mi_ctx_create.argtypes = [ip, ctypes.c_int, ip, ctypes.c_int, dp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+        L.mi_ctx_destroy.argtypes = [vp]
+        L.mi_ctx_destroy.restype = None
+        L.mi_ctx_nao.argtypes = [vp]
+        L.mi_int1e.argtypes = [vp, vp, vp, vp, vp, dp, vp]
+        L.mi_eri_prepare.argtypes = [vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp]
+        L.mi_eri_get_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
+        L.mi_build_jk.argtypes = [vp, vp, ctypes.c_int, vp, vp, vp]
+        L.mi_time_jk_kernel.argtypes = [vp, vp, ctypes.c_int, dp, vp]
+        L.mi_diis_errvec.argtypes = [vp, vp, vp, vp]
+        L.mi_diis_combine.argtypes = [vp, vp, dp, ctypes.c_int, vp, vp]
+        L.mi_diis_dots.argtypes = [vp, vp, vp, ctypes.c_int, dp, vp]
+        L.mi_c2s_table.argtypes = [ctypes.c_int, dp]
+        L.mi_rys_roots_host.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise EngineError(lib().mi_last_error().decode())
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise EngineError("no MI355X/HIP device visible: the SCF engine runs on the GPU only (no CPU fallback)")
+
+
+def c2s_table(l):
+    out = np.zeros(((l + 1) * (l + 2) // 2, 2 * l + 1))
+    _check(lib().mi_c2s_table(l, _dp(out)))
+    return out
+
+
+def rys_roots(n, x):
+    r, w = np.zeros(n), np.zeros(n)
+    _check(lib().mi_rys_roots_host(n, float(x), _dp(r), _dp(w)))
+    return r, w
+
+
+class Engine:
+    """One engine context = one molecule/basis on one GPU (rows a2-a6, a10 of SURVEY.md section 8)."""
+
+    def __init__(self, mol, device=None):
+        require_gpu()
+        self.mol = mol
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else device.index)
+        self._atm = np.ascontiguousarray(mol._atm, dtype=np.int32)
+        self._bas = np.ascontiguousarray(mol._bas, dtype=np.int32)
+        self._env = np.ascontiguousarray(mol._env, dtype=np.float64)
+        self.nao = mol.nao
+        h = ctypes.c_void_p()
+        ip = ctypes.POINTER(ctypes.c_int32)
+        _check(lib().mi_ctx_create(self._atm.ctypes.data_as(ip), len(self._atm), self._bas.ctypes.data_as(ip),
+                                   len(self._bas), _dp(self._env), len(self._env), self.device.index, ctypes.byref(h)))
+        self._h = h
+        self.eri_ready = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().mi_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    close = __del__
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    # --- row a2 ------------------------------------------------------------------------------
+    def int1e(self, with_dipole=False, origin=None):
+        n = self.nao
+        S, T, V = self._new(n, n), self._new(n, n), self._new(n, n)
+        dip = self._new(3, n, n) if with_dipole else None
+        org = np.zeros(3) if origin is None else np.ascontiguousarray(origin, dtype=np.float64)
+        with torch.cuda.device(self.device):
+            _check(lib().mi_int1e(self._h, S.data_ptr(), T.data_ptr(), V.data_ptr(),
+                                  dip.data_ptr() if dip is not None else None, _dp(org), self._stream()))
+        return (S, T, V, dip) if with_dipole else (S, T, V)
+
+    # --- rows a3, a4 ---------------------------------------------------------------------------
+    def prepare_eri(self, tol=1e-13, rank=0, nranks=1):
+        with torch.cuda.device(self.device):
+            _check(lib().mi_eri_prepare(self._h, float(tol), int(rank), int(nranks), self._stream()))
+        self.eri_ready = True
+        return self.stats()
+
+    def stats(self):
+        s = _Stats()
+        _check(lib().mi_eri_get_stats(self._h, ctypes.byref(s)))
+        return {k: getattr(s, k) for k, _ in _Stats._fields_}
+
+    # --- rows a5, a6 ---------------------------------------------------------------------------
+    def get_jk(self, dm, with_j=True, with_k=True):
+        if not self.eri_ready:
+            self.prepare_eri()
+        dm = torch.as_tensor(dm, dtype=torch.float64, device=self.device).contiguous()
+        squeeze = dm.dim() == 2
+        if squeeze:
+            dm = dm.unsqueeze(0)
+        J = torch.empty_like(dm) if with_j else None
+        K = torch.empty_like(dm) if with_k else None
+        with torch.cuda.device(self.device):
+            _check(lib().mi_build_jk(self._h, dm.data_ptr(), dm.shape[0], J.data_ptr() if with_j else None,
+                                     K.data_ptr() if with_k else None, self._stream()))
+        if squeeze:
+            J = J[0] if with_j else None
+            K = K[0] if with_k else None
+        return J, K
+
+    def time_jk_kernel(self, dm, reps=20):
+        dm = torch.as_tensor(dm, dtype=torch.float64, device=self.device).contiguous()
+        ms = ctypes.c_double()
+        with torch.cuda.device(self.device):
+            _check(lib().mi_time_jk_kernel(self._h, dm.data_ptr(), reps, ctypes.byref(ms), self._stream()))
+        return ms.value
+
+    # --- row a10 -------------------------------------------------------------------------------
+    def diis_errvec(self, sdf, out):
+        _check(lib().mi_diis_errvec(self._h, sdf.data_ptr(), out.data_ptr(), self._stream()))
+
+    def diis_combine(self, hist, coef, out):
+        c = np.ascontiguousarray(coef, dtype=np.float64)
+        _check(lib().mi_diis_combine(self._h, hist.data_ptr(), _dp(c), len(c), out.data_ptr(), self._stream()))
+
+    def diis_dots(self, hist_e, e, n):
+        out = np.zeros(n)
+        _check(lib().mi_diis_dots(self._h, hist_e.data_ptr(), e.data_ptr(), n, _dp(out), self._stream()))
+        return out
+
+
+_ENGINES = {}
+
+
+def engine_for(mol):
+    key = id(mol)
+    eng = _ENGINES.get(key)
+    if eng is None or eng.mol is not mol or not np.array_equal(eng._env, mol._env):
+        eng = Engine(mol)
+        _ENGINES.clear()
+        _ENGINES[key] = eng
+    return eng
+
+
+def intor(mol, name, **kw):
+    """`mol.intor('int1e_ovlp' | 'int1e_kin' | 'int1e_nuc' | 'int1e_r')` on the GPU, returned as NumPy."""
+    eng = engine_for(mol)
+    key = name.replace("_sph", "")
+    if key == "int1e_r":
+        return eng.int1e(with_dipole=True, origin=kw.get("origin"))[3].cpu().numpy()
+    S, T, V = eng.int1e()
+    table = {"int1e_ovlp": S, "int1e_kin": T, "int1e_nuc": V}
+    if key not in table:
+        raise NotImplementedError(f"intor('{name}') is outside the Fock-build hot path")
+    return table[key].cpu().numpy()

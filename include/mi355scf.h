@@ -1,0 +1,102 @@
+/*
+ * mi355scf.h -- C ABI of the MI355X (gfx950) SCF Fock-build engine.
+ *
+ * Drop-in boundary.  The reference has no native plugin ABI: its scripts call
+ * the Python surface of pyscf / gpu4pyscf, which in turn bind C libraries (libcint / libcvhf /
+ * gpu4pyscf's libgvhf_rys, libgdft) through ctypes.  Each entry point below names the reference call
+ * site that triggers it and the upstream C routine it stands in for [MEM = un-vendored upstream,
+ * named from memory, not present under /root/reference].
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every function returns 0 on success and a
+ * negative code on failure (text via mi_last_error()); no exceptions cross the ABI.  `atm`, `bas`,
+ * `env` follow the libcint layout (atm[natm][6], bas[nbas][8], env[]) that a PySCF-shaped Mole already
+ * holds; only nctr == 1 shells with l <= 3 are accepted.  Pointers named d_* are DEVICE pointers
+ * (e.g. torch.Tensor.data_ptr()) on the context's device; everything else is host memory.  `stream` is
+ * a hipStream_t passed as void* (NULL = default stream).  All matrices are row-major [nao][nao] FP64.
+ * A context is bound to one GPU and is not thread-safe; use one context per device/process.
+ */
+#ifndef MI355SCF_H
+#define MI355SCF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_ctx mi_ctx;
+
+/* Last error text of the calling thread. */
+const char *mi_last_error(void);
+
+/* ABI version of this header/library pair. */
+int mi_abi_version(void);
+
+/* Create / destroy an engine context for one molecule+basis on GPU `device_id`.
+ * Replaces: gto.Mole.build() handing _atm/_bas/_env to libcint (templates/calculate_energy.py:89-101;
+ * templates/optimize_geometry.py:48-54). */
+int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, int nbas, const double *env,
+                  int nenv, int device_id, mi_ctx **out);
+void mi_ctx_destroy(mi_ctx *ctx);
+int mi_ctx_nao(const mi_ctx *ctx);
+
+/* One-electron integrals into device buffers (any of them may be NULL): overlap S, kinetic T, nuclear
+ * attraction V, dipole d_dip[3][nao][nao] about `origin` (host double[3], NULL = zero).
+ * Replaces: libcint int1e_ovlp_sph / int1e_kin_sph / int1e_nuc_sph / int1e_r_sph [MEM], reached from
+ * mf.kernel() -> get_ovlp/get_hcore (templates/calculate_energy.py:155,205) and mf.dip_moment
+ * (templates/calculate_energy.py:253). */
+int mi_int1e(mi_ctx *ctx, double *d_S, double *d_T, double *d_V, double *d_dip, const double *origin,
+             void *stream);
+
+/* Evaluate the Schwarz-screened symmetry-unique four-centre ERIs once with the Rys-quadrature kernels
+ * and keep them resident in HBM as 8x8x8x8 AO tiles.  `tol` is the Schwarz threshold
+ * (PySCF direct_scf_tol = 1e-13 [MEM]).  (rank, nranks) select this process's shard of the tile runs
+ * (SURVEY.md section 8e); pass (0, 1) for a single GPU.
+ * Replaces: libcint int2e_sph + libcvhf CVHFnr_int2e_q_cond [MEM] / gpu4pyscf libgvhf_rys [MEM],
+ * reached from mf.kernel() -> get_jk (templates/calculate_energy.py:155; optimize_geometry.py:90). */
+int mi_eri_prepare(mi_ctx *ctx, double tol, int rank, int nranks, void *stream);
+
+/* Statistics of the resident ERI store. */
+typedef struct {
+    int64_t n_tiles;          /* tiles resident on this rank                                    */
+    int64_t n_runs;           /* (J,K,L) runs                                                    */
+    int64_t stored_bytes;     /* bytes of tile payload streamed per J/K build on this rank       */
+    int64_t n_unique_eri;     /* symmetry-unique (i>=j,k>=l,ij>=kl) ERIs inside the resident tiles */
+    int64_t n_quartets;       /* shell quartets evaluated                                       */
+    double  seconds_eri;      /* wall time of the one-off ERI evaluation                        */
+} mi_eri_stats;
+int mi_eri_get_stats(const mi_ctx *ctx, mi_eri_stats *out);
+
+/* Coulomb and exchange matrices from the resident ERIs for n_dm density matrices:
+ *   J_ij = sum_kl (ij|kl) D_kl,   K_ik = sum_jl (ij|kl) D_jl.
+ * d_D, d_J, d_K: [n_dm][nao][nao]; d_J or d_K may be NULL to skip that matrix.  On a sharded context
+ * the result is this rank's partial sum; the caller all-reduces (RCCL) across ranks.
+ * Replaces: libcvhf CVHFnr_direct_drv with CVHFnrs8_ji_s2kl / CVHFnrs8_li_s2kj [MEM] / gpu4pyscf
+ * RYS_build_jk [MEM], reached from get_jk / get_veff inside mf.kernel(). */
+int mi_build_jk(mi_ctx *ctx, const double *d_D, int n_dm, double *d_J, double *d_K, void *stream);
+
+/* Time `reps` back-to-back launches of the J/K digestion kernel alone with HIP events on `stream`
+ * and return the average milliseconds per launch (bench.py's roofline leg). */
+int mi_time_jk_kernel(mi_ctx *ctx, const double *d_D, int reps, double *ms_per_launch, void *stream);
+
+/* DIIS (Pulay) helpers on device: given F, D, S form e = S D F - F D S ... */
+/* err = A - A^T written in place of nothing: d_err[nao*nao] = d_SDF - d_SDF^T (fused epilogue). */
+int mi_diis_errvec(mi_ctx *ctx, const double *d_SDF, double *d_err, void *stream);
+/* d_out = sum_i coef[i] * d_hist[i]  (hist: n matrices of nao*nao, contiguous). coef on host. */
+int mi_diis_combine(mi_ctx *ctx, const double *d_hist, const double *coef, int n, double *d_out,
+                    void *stream);
+/* Gram matrix row: out[i] = <d_hist_e[i], d_e> for i < n (host output, synchronises `stream`). */
+int mi_diis_dots(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int n, double *out,
+                 void *stream);
+
+/* Real-solid-harmonic coefficient table used by the kernels: out[ncart(l)][2l+1] (host). */
+int mi_c2s_table(int l, double *out);
+
+/* Rys roots/weights as evaluated by the device tables, for tests: roots[n], weights[n] (host). */
+int mi_rys_roots_host(int nroots, double x, double *roots, double *weights);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355SCF_H */
