@@ -1,0 +1,1 @@
+from mi355scf.dft import RKS  # noqa: F401

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/energies.json with the CPU oracle (oracle/oracle.py).  The reference holds no
+golden vectors for this path, so these are oracle-generated fixtures."""
+import json, os, sys, time
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "computational-chemistry-ai_amd", "python")); sys.path.insert(0, ROOT)
+from mi355scf.mole import Mole
+from mi355scf import fixtures
+from oracle import oracle as orc
+
+out = {}
+path = os.path.join(HERE, "energies.json")
+if os.path.exists(path):
+    out = json.load(open(path))
+cases = {
+    "h2o_sto3g_rhf": (fixtures.H2O, "sto-3g"),
+    "h2o_631g_rhf": (fixtures.H2O, "6-31g"),
+    "h2o_ccpvdz_rhf": (fixtures.H2O, "cc-pvdz"),
+    "h2co_631gd_rhf": (fixtures.H2CO, "6-31g(d)"),
+    "benzene_ccpvdz_rhf": (fixtures.BENZENE, "cc-pvdz"),
+}
+for key, (atom, basis) in cases.items():
+    if key in out and "--force" not in sys.argv:
+        continue
+    mol = Mole(atom=atom, basis=basis).build()
+    t = time.time()
+    r = orc.rhf(mol, verbose=True)
+    out[key] = dict(e_tot=r["e_tot"], converged=bool(r["converged"]), cycles=r["cycles"], nao=mol.nao,
+                    seconds=round(time.time() - t, 2), threads=orc.Oracle.num_threads())
+    print(key, out[key])
+    json.dump(out, open(path, "w"), indent=1)
