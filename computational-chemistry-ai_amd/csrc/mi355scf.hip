@@ -1358,3 +1358,354 @@ extern "C" int mi_diis_dots(mi_ctx *c, const double *d_hist_e, const double *d_e
     HIPCHK(hipStreamSynchronize(st));
     return 0;
 }
+
+// =================================================================================================
+// DFT: Becke weights, AO values on the grid, density, XC functionals, weighted AOs (rows a7-a9)
+// =================================================================================================
+#define MAXATM_LDS 1024
+
+struct BeckeArgs {
+    const double *coords; // [ng][3]
+    const int32_t *atom_of;
+    const double *vol;
+    const double *atom_xyz; // [natm][3]
+    const double *adj;      // [natm][natm] Treutler adjustment a_ij
+    int natm;
+    int64_t ng;
+    double *w;
+};
+
+// One thread per grid point.  P_i = prod_{j != i} s(mu_ij), 3x iterated Becke polynomial, with
+// mu' = mu + a_ij (1 - mu^2); w = vol * P_owner / sum_i P_i.
+__global__ __launch_bounds__(256) void becke_weights_kernel(BeckeArgs A)
+{
+    extern __shared__ double sh[]; // atom coordinates
+    for (int i = threadIdx.x; i < A.natm * 3; i += blockDim.x) sh[i] = A.atom_xyz[i];
+    __syncthreads();
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= A.ng) return;
+    const double x = A.coords[3 * g], y = A.coords[3 * g + 1], z = A.coords[3 * g + 2];
+    const int own = A.atom_of[g];
+    double psum = 0.0, pown = 0.0;
+    for (int i = 0; i < A.natm; i++) {
+        double dxi = x - sh[3 * i], dyi = y - sh[3 * i + 1], dzi = z - sh[3 * i + 2];
+        double ri = sqrt(dxi * dxi + dyi * dyi + dzi * dzi);
+        double p = 1.0;
+        for (int j = 0; j < A.natm; j++) {
+            if (j == i) continue;
+            double dxj = x - sh[3 * j], dyj = y - sh[3 * j + 1], dzj = z - sh[3 * j + 2];
+            double rj = sqrt(dxj * dxj + dyj * dyj + dzj * dzj);
+            double ax = sh[3 * i] - sh[3 * j], ay = sh[3 * i + 1] - sh[3 * j + 1], az = sh[3 * i + 2] - sh[3 * j + 2];
+            double mu = (ri - rj) * rsqrt(ax * ax + ay * ay + az * az);
+            mu = mu + A.adj[i * A.natm + j] * (1.0 - mu * mu);
+            mu = (3.0 - mu * mu) * mu * 0.5;
+            mu = (3.0 - mu * mu) * mu * 0.5;
+            mu = (3.0 - mu * mu) * mu * 0.5;
+            p *= 0.5 * (1.0 - mu);
+        }
+        psum += p;
+        if (i == own) pown = p;
+    }
+    A.w[g] = A.vol[g] * pown / psum;
+}
+
+extern "C" int mi_grid_becke(mi_ctx *c, const double *d_coords, const int32_t *d_atom_of, const double *d_vol, int64_t ng,
+                             const double *d_adjust, double *d_weights, void *stream)
+{
+    if (!c || !d_coords || !d_atom_of || !d_vol || !d_adjust || !d_weights) return fail("mi_grid_becke: null argument");
+    if (c->natm > MAXATM_LDS) return fail("mi_grid_becke: too many atoms");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<double> xyz(c->natm * 3);
+    for (int i = 0; i < c->natm; i++)
+        for (int d = 0; d < 3; d++) xyz[3 * i + d] = c->env[c->atm[i * ATM_SLOTS + 1] + d];
+    double *d_xyz = nullptr;
+    HIPCHK(hipMalloc(&d_xyz, sizeof(double) * xyz.size()));
+    HIPCHK(hipMemcpy(d_xyz, xyz.data(), sizeof(double) * xyz.size(), hipMemcpyHostToDevice));
+    BeckeArgs A{d_coords, d_atom_of, d_vol, d_xyz, d_adjust, c->natm, ng, d_weights};
+    hipLaunchKernelGGL(becke_weights_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), sizeof(double) * 3 * c->natm,
+                       (hipStream_t)stream, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    hipFree(d_xyz);
+    return 0;
+}
+
+struct AoArgs {
+    const int32_t *atm, *bas;
+    const double *env;
+    const int *shell_ao;
+    const double *c2s;
+    int c2s_off[LMAX + 2];
+    int nbas, nao, deriv;
+    const double *coords; // [ng][3]
+    int64_t ng;
+    double *ao;           // [4 or 1][nao][ng]
+};
+
+// One thread per grid point, loop over shells (wave-uniform shell data -> scalar loads); stores are
+// coalesced along the grid index.
+__global__ __launch_bounds__(256) void eval_ao_kernel(AoArgs A)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= A.ng) return;
+    const double gx = A.coords[3 * g], gy = A.coords[3 * g + 1], gz = A.coords[3 * g + 2];
+    const size_t comp = (size_t)A.nao * A.ng;
+    for (int ish = 0; ish < A.nbas; ish++) {
+        const int32_t *b = A.bas + ish * BAS_SLOTS;
+        const int l = b[1], np = b[2];
+        const double *R = A.env + A.atm[b[0] * ATM_SLOTS + 1];
+        const double x = gx - R[0], y = gy - R[1], z = gz - R[2];
+        const double r2 = x * x + y * y + z * z;
+        double rad = 0.0, drad = 0.0;
+        for (int p = 0; p < np; p++) {
+            double a = A.env[b[5] + p];
+            double e = A.env[b[6] + p] * exp(-a * r2);
+            rad += e;
+            drad -= 2.0 * a * e;
+        }
+        const double *c2s = A.c2s + A.c2s_off[l];
+        const int ns = 2 * l + 1;
+        double s[2 * LMAX + 1], sx[2 * LMAX + 1], sy[2 * LMAX + 1], sz[2 * LMAX + 1];
+        for (int m = 0; m < ns; m++) s[m] = sx[m] = sy[m] = sz[m] = 0.0;
+        double px[LMAX + 1], py[LMAX + 1], pz[LMAX + 1];
+        px[0] = py[0] = pz[0] = 1.0;
+        for (int k = 1; k <= l; k++) { px[k] = px[k - 1] * x; py[k] = py[k - 1] * y; pz[k] = pz[k - 1] * z; }
+        int k = 0;
+        for (int lx = l; lx >= 0; lx--)
+            for (int ly = l - lx; ly >= 0; ly--, k++) {
+                int lz = l - lx - ly;
+                double v = px[lx] * py[ly] * pz[lz];
+                double dx = lx ? lx * px[lx - 1] * py[ly] * pz[lz] : 0.0;
+                double dy = ly ? ly * px[lx] * py[ly - 1] * pz[lz] : 0.0;
+                double dz = lz ? lz * px[lx] * py[ly] * pz[lz - 1] : 0.0;
+                for (int m = 0; m < ns; m++) {
+                    double cc = c2s[k * ns + m];
+                    s[m] += cc * v; sx[m] += cc * dx; sy[m] += cc * dy; sz[m] += cc * dz;
+                }
+            }
+        const int ao0 = A.shell_ao[ish];
+        for (int m = 0; m < ns; m++) {
+            size_t o = (size_t)(ao0 + m) * A.ng + g;
+            A.ao[o] = rad * s[m];
+            if (A.deriv) {
+                A.ao[comp + o] = drad * x * s[m] + rad * sx[m];
+                A.ao[2 * comp + o] = drad * y * s[m] + rad * sy[m];
+                A.ao[3 * comp + o] = drad * z * s[m] + rad * sz[m];
+            }
+        }
+    }
+}
+
+extern "C" int mi_eval_ao(mi_ctx *c, const double *d_coords, int64_t ng, int deriv, double *d_ao, void *stream)
+{
+    if (!c || !d_coords || !d_ao) return fail("mi_eval_ao: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    AoArgs A;
+    A.atm = c->d_atm; A.bas = c->d_bas; A.env = c->d_env; A.shell_ao = c->d_shell_ao; A.c2s = c->d_c2s;
+    for (int i = 0; i <= LMAX + 1; i++) A.c2s_off[i] = c->c2s_off[i];
+    A.nbas = c->nbas; A.nao = c->nao; A.deriv = deriv; A.coords = d_coords; A.ng = ng; A.ao = d_ao;
+    hipLaunchKernelGGL(eval_ao_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// rho[0][g] = sum_mu ao0*C ; rho[1..3][g] = 2 sum_mu ao_k*C   with C = D @ ao0
+__global__ __launch_bounds__(256) void xc_rho_kernel(const double *ao, const double *C, int nao, int64_t ng, int deriv, double *rho)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const size_t comp = (size_t)nao * ng;
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    for (int m = 0; m < nao; m++) {
+        size_t o = (size_t)m * ng + g;
+        double cv = C[o];
+        r0 = fma(ao[o], cv, r0);
+        if (deriv) {
+            r1 = fma(ao[comp + o], cv, r1);
+            r2 = fma(ao[2 * comp + o], cv, r2);
+            r3 = fma(ao[3 * comp + o], cv, r3);
+        }
+    }
+    rho[g] = r0;
+    if (deriv) { rho[ng + g] = 2 * r1; rho[2 * ng + g] = 2 * r2; rho[3 * ng + g] = 2 * r3; }
+}
+
+extern "C" int mi_xc_rho(mi_ctx *c, const double *d_ao, const double *d_C, int64_t ng, int deriv, double *d_rho, void *stream)
+{
+    if (!c || !d_ao || !d_C || !d_rho) return fail("mi_xc_rho: null argument");
+    hipLaunchKernelGGL(xc_rho_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_ao, d_C, c->nao, ng, deriv, d_rho);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- forward-mode dual numbers: value, d/drho, d/dsigma
+struct D2 {
+    double v, r, s;
+    __device__ D2() {}
+    __device__ D2(double a) : v(a), r(0), s(0) {}
+    __device__ D2(double a, double b, double c) : v(a), r(b), s(c) {}
+};
+__device__ inline D2 operator+(D2 a, D2 b) { return D2(a.v + b.v, a.r + b.r, a.s + b.s); }
+__device__ inline D2 operator-(D2 a, D2 b) { return D2(a.v - b.v, a.r - b.r, a.s - b.s); }
+__device__ inline D2 operator-(D2 a) { return D2(-a.v, -a.r, -a.s); }
+__device__ inline D2 operator*(D2 a, D2 b) { return D2(a.v * b.v, a.r * b.v + a.v * b.r, a.s * b.v + a.v * b.s); }
+__device__ inline D2 operator/(D2 a, D2 b)
+{
+    double iv = 1.0 / b.v, q = a.v * iv;
+    return D2(q, (a.r - q * b.r) * iv, (a.s - q * b.s) * iv);
+}
+__device__ inline D2 chain(D2 a, double f, double df) { return D2(f, df * a.r, df * a.s); }
+__device__ inline D2 dexp(D2 a) { double e = exp(a.v); return chain(a, e, e); }
+__device__ inline D2 dlog(D2 a) { return chain(a, log(a.v), 1.0 / a.v); }
+__device__ inline D2 dsqrt(D2 a) { double s = sqrt(a.v); return chain(a, s, 0.5 / s); }
+__device__ inline D2 dpow(D2 a, double p) { double f = pow(a.v, p); return chain(a, f, p * f / a.v); }
+__device__ inline D2 datan(D2 a) { return chain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+__device__ inline D2 dasinh(D2 a) { return chain(a, asinh(a.v), rsqrt(1.0 + a.v * a.v)); }
+
+enum { XC_SLATER = 1, XC_B88 = 2, XC_VWN_RPA = 3, XC_VWN5 = 4, XC_LYP = 5, XC_PBE_X = 6, XC_PBE_C = 7 };
+
+__device__ inline D2 f_slater(D2 rho) { return D2(-0.7385587663820224) * dpow(rho, 4.0 / 3.0); } // -(3/4)(3/pi)^(1/3)
+
+__device__ inline D2 f_b88(D2 rho, D2 sig)
+{
+    const double beta = 0.0042;
+    D2 rs = rho * D2(0.5);                 // one spin channel
+    D2 r43 = dpow(rs, 4.0 / 3.0);
+    D2 x = dsqrt(sig * D2(0.25) + D2(1e-300)) / r43;
+    D2 corr = D2(-beta) * r43 * x * x / (D2(1.0) + D2(6.0 * beta) * x * dasinh(x));
+    return f_slater(rho) + D2(2.0) * corr;
+}
+
+__device__ inline D2 f_vwn(D2 rho, double A, double x0, double b, double c)
+{
+    D2 rs = dpow(D2(0.75 / M_PI) / rho, 1.0 / 3.0);
+    D2 x = dsqrt(rs);
+    D2 X = x * x + D2(b) * x + D2(c);
+    double X0 = x0 * x0 + b * x0 + c, Q = sqrt(4 * c - b * b);
+    D2 at = datan(D2(Q) / (D2(2.0) * x + D2(b)));
+    D2 xm = x - D2(x0);
+    D2 eps = D2(A) * (dlog(x * x / X) + D2(2 * b / Q) * at - D2(b * x0 / X0) * (dlog(xm * xm / X) + D2(2 * (b + 2 * x0) / Q) * at));
+    return rho * eps;
+}
+
+__device__ inline D2 f_lyp(D2 rho, D2 sig)
+{
+    const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349;
+    const double CF = 2.871234000188191; // (3/10)(3 pi^2)^(2/3)
+    D2 t = dpow(rho, -1.0 / 3.0);
+    D2 Dn = D2(1.0) + D2(d) * t;
+    D2 om = dexp(D2(-c) * t) / Dn * dpow(rho, -11.0 / 3.0);
+    D2 dl = D2(c) * t + D2(d) * t / Dn;
+    D2 br = D2(CF) * dpow(rho, 14.0 / 3.0) - rho * rho * sig * (D2(1.0 / 24.0) + D2(7.0 / 72.0) * dl);
+    return D2(-a) * rho / Dn - D2(a * b) * om * br;
+}
+
+__device__ inline D2 f_pbe_x(D2 rho, D2 sig)
+{
+    const double kappa = 0.804, mu = 0.06672455060314922 * M_PI * M_PI / 3.0;
+    D2 kf = dpow(D2(3.0 * M_PI * M_PI) * rho, 1.0 / 3.0);
+    D2 s2 = sig / (D2(4.0) * kf * kf * rho * rho);
+    D2 F = D2(1.0 + kappa) - D2(kappa) / (D2(1.0) + D2(mu / kappa) * s2);
+    return f_slater(rho) * F;
+}
+
+__device__ inline D2 f_pbe_c(D2 rho, D2 sig)
+{
+    const double beta = 0.06672455060314922, gamma = 0.031090690869654895;
+    const double A = 0.031090690869654895, a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
+    D2 rs = dpow(D2(0.75 / M_PI) / rho, 1.0 / 3.0);
+    D2 x = dsqrt(rs);
+    D2 ec = D2(-2 * A) * (D2(1.0) + D2(a1) * rs) *
+            dlog(D2(1.0) + D2(1.0) / (D2(2 * A) * (D2(b1) * x + D2(b2) * rs + D2(b3) * rs * x + D2(b4) * rs * rs)));
+    D2 kf = dpow(D2(3.0 * M_PI * M_PI) * rho, 1.0 / 3.0);
+    D2 ks2 = D2(4.0 / M_PI) * kf;
+    D2 t2 = sig / (D2(4.0) * ks2 * rho * rho);
+    D2 Aa = D2(beta / gamma) / (dexp(-ec / D2(gamma)) - D2(1.0));
+    D2 At2 = Aa * t2;
+    D2 H = D2(gamma) * dlog(D2(1.0) + D2(beta / gamma) * t2 * (D2(1.0) + At2) / (D2(1.0) + At2 + At2 * At2));
+    return rho * (ec + H);
+}
+
+struct XcSpec { int n; int kind[8]; double coef[8]; };
+
+// exc[g] = e(rho,sigma) per volume; wv[0] = 0.5 w de/drho ; wv[1..3] = 2 w de/dsigma * grad rho
+__global__ __launch_bounds__(256) void xc_eval_kernel(XcSpec X, const double *rho, const double *w, int64_t ng, int gga,
+                                                      double *exc, double *wv, double *vrho_out, double *vsig_out)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    double r = rho[g];
+    double gx = gga ? rho[ng + g] : 0.0, gy = gga ? rho[2 * ng + g] : 0.0, gz = gga ? rho[3 * ng + g] : 0.0;
+    double e = 0.0, vr = 0.0, vs = 0.0;
+    if (r > 1e-10) {
+        D2 R(r, 1.0, 0.0), S(gx * gx + gy * gy + gz * gz, 0.0, 1.0);
+        D2 acc(0.0);
+        for (int t = 0; t < X.n; t++) {
+            D2 f;
+            switch (X.kind[t]) {
+            case XC_SLATER: f = f_slater(R); break;
+            case XC_B88: f = f_b88(R, S); break;
+            case XC_VWN_RPA: f = f_vwn(R, 0.0310907, -0.409286, 13.0720, 42.7198); break;
+            case XC_VWN5: f = f_vwn(R, 0.0310907, -0.10498, 3.72744, 12.9352); break;
+            case XC_LYP: f = f_lyp(R, S); break;
+            case XC_PBE_X: f = f_pbe_x(R, S); break;
+            case XC_PBE_C: f = f_pbe_c(R, S); break;
+            default: f = D2(0.0);
+            }
+            acc = acc + D2(X.coef[t]) * f;
+        }
+        e = acc.v; vr = acc.r; vs = acc.s;
+    }
+    if (exc) exc[g] = e;
+    if (vrho_out) vrho_out[g] = vr;
+    if (vsig_out) vsig_out[g] = vs;
+    if (wv) {
+        double ww = w[g];
+        wv[g] = 0.5 * ww * vr;
+        if (gga) {
+            double f = 2.0 * ww * vs;
+            wv[ng + g] = f * gx; wv[2 * ng + g] = f * gy; wv[3 * ng + g] = f * gz;
+        }
+    }
+}
+
+extern "C" int mi_xc_eval(const int32_t *kinds, const double *coefs, int nterms, const double *d_rho, const double *d_w,
+                          int64_t ng, int gga, double *d_exc, double *d_wv, double *d_vrho, double *d_vsigma, void *stream)
+{
+    if (nterms < 0 || nterms > 8) return fail("mi_xc_eval: at most 8 functional terms");
+    if (!d_rho || (d_wv && !d_w)) return fail("mi_xc_eval: null argument");
+    XcSpec X{};
+    X.n = nterms;
+    for (int i = 0; i < nterms; i++) {
+        if (kinds[i] < XC_SLATER || kinds[i] > XC_PBE_C) return fail("mi_xc_eval: unknown functional id %d", kinds[i]);
+        X.kind[i] = kinds[i]; X.coef[i] = coefs[i];
+    }
+    hipLaunchKernelGGL(xc_eval_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, d_rho, d_w, ng, gga,
+                       d_exc, d_wv, d_vrho, d_vsigma);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// aow[mu][g] = ao0*wv0 + sum_k ao_k*wv_k
+__global__ __launch_bounds__(256) void xc_aow_kernel(const double *ao, const double *wv, int nao, int64_t ng, int gga, double *aow)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const size_t comp = (size_t)nao * ng;
+    double w0 = wv[g], w1 = gga ? wv[ng + g] : 0, w2 = gga ? wv[2 * ng + g] : 0, w3 = gga ? wv[3 * ng + g] : 0;
+    for (int m = blockIdx.y; m < nao; m += gridDim.y) {
+        size_t o = (size_t)m * ng + g;
+        double v = ao[o] * w0;
+        if (gga) v += ao[comp + o] * w1 + ao[2 * comp + o] * w2 + ao[3 * comp + o] * w3;
+        aow[o] = v;
+    }
+}
+
+extern "C" int mi_xc_aow(mi_ctx *c, const double *d_ao, const double *d_wv, int64_t ng, int gga, double *d_aow, void *stream)
+{
+    if (!c || !d_ao || !d_wv || !d_aow) return fail("mi_xc_aow: null argument");
+    dim3 grid((unsigned)((ng + 255) / 256), (unsigned)std::min(c->nao, 64));
+    hipLaunchKernelGGL(xc_aow_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_ao, d_wv, c->nao, ng, gga, d_aow);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -1,9 +1,119 @@
-"""RKS placeholder; replaced by the Becke-grid XC implementation (rows a7-a9)."""
+"""Restricted Kohn-Sham on the MI355X engine: `pyscf.dft.RKS` / `gpu4pyscf.dft.RKS` (rows a7-a9, a12).
+
+Reference call sites: `templates/calculate_energy.py:148-149,163-164,202-203` (`mf = RKS(mol); mf.xc = method`),
+`templates/optimize_geometry.py:72-73` (xc assigned AFTER `.to_gpu()`).  B3LYP follows libxc's
+HYB_GGA_XC_B3LYP (VWN-RPA) as PySCF >= 2.3 does [MEM].  XC quadrature: HIP kernels for AO values,
+density, functional (forward-mode dual numbers) and weighted AOs; the two dense contractions per grid
+block are rocBLAS DGEMMs (FP64 MFMA) through torch.matmul.
+"""
+import numpy as np
+import torch
+
+from .grids import Grids
 from .scf import RHF
+
+XC_IDS = {"slater": 1, "b88": 2, "vwn_rpa": 3, "vwn5": 4, "lyp": 5, "pbe_x": 6, "pbe_c": 7}
+
+
+def parse_xc(name):
+    """-> (hyb, [(coef, kind_id)], is_gga)"""
+    key = str(name).upper().replace("-", "").replace("_", "").replace(" ", "")
+    table = {
+        "HF": (1.0, []),
+        "B3LYP": (0.2, [(0.08, "slater"), (0.72, "b88"), (0.19, "vwn_rpa"), (0.81, "lyp")]),
+        "B3LYPG": (0.2, [(0.08, "slater"), (0.72, "b88"), (0.19, "vwn_rpa"), (0.81, "lyp")]),
+        "B3LYP5": (0.2, [(0.08, "slater"), (0.72, "b88"), (0.19, "vwn5"), (0.81, "lyp")]),
+        "PBE": (0.0, [(1.0, "pbe_x"), (1.0, "pbe_c")]),
+        "PBE,PBE": (0.0, [(1.0, "pbe_x"), (1.0, "pbe_c")]),
+        "PBE0": (0.25, [(0.75, "pbe_x"), (1.0, "pbe_c")]),
+        "LDA": (0.0, [(1.0, "slater"), (1.0, "vwn5")]),
+        "LDA,VWN": (0.0, [(1.0, "slater"), (1.0, "vwn5")]),
+        "SVWN": (0.0, [(1.0, "slater"), (1.0, "vwn5")]),
+        "LDA,VWNRPA": (0.0, [(1.0, "slater"), (1.0, "vwn_rpa")]),
+        "BLYP": (0.0, [(1.0, "b88"), (1.0, "lyp")]),
+        "B88,LYP": (0.0, [(1.0, "b88"), (1.0, "lyp")]),
+    }
+    if key not in table:
+        raise NotImplementedError(f"xc functional '{name}' is not implemented on the MI355X engine "
+                                  f"(have {sorted(table)}); meta-GGAs such as M06-2X are out of scope (SURVEY.md 8f-4)")
+    hyb, terms = table[key]
+    gga = any(k not in ("slater", "vwn_rpa", "vwn5") for _c, k in terms)
+    return hyb, [(c, XC_IDS[k]) for c, k in terms], gga
 
 
 class RKS(RHF):
     xc = "LDA,VWN"
+    grid_block = 32768
 
-    def kernel(self, dm0=None, **kw):
-        raise NotImplementedError("XC quadrature kernels not built yet")
+    def __init__(self, mol, xc=None):
+        super().__init__(mol)
+        if xc is not None:
+            self.xc = xc
+        self.grids = Grids(mol)
+        self._nelec_grid = None
+
+    def reset(self, mol=None):
+        super().reset(mol)
+        self.grids = Grids(self.mol)
+        lvl = getattr(self, "_grid_level", None)
+        if lvl is not None:
+            self.grids.level = lvl
+        return self
+
+    def _setup(self):
+        super()._setup()
+        if self.grids.weights is None or self.grids.mol is not self.mol:
+            self.grids.mol = self.mol
+            self.grids.build(engine=self.engine)
+            self._log(4, f"XC grid: {self.grids.size} points (level {self.grids.level})")
+
+    def nr_rks(self, dm):
+        """(N_elec, E_xc, V_xc) on device for a closed-shell density (numint.nr_rks [MEM])."""
+        eng = self.engine
+        hyb, terms, gga = parse_xc(self.xc)
+        n = eng.nao
+        coords, weights = self.grids.coords, self.grids.weights
+        ng = coords.shape[0]
+        vmat = torch.zeros(n, n, dtype=torch.float64, device=eng.device)
+        nelec = torch.zeros((), dtype=torch.float64, device=eng.device)
+        exc = torch.zeros((), dtype=torch.float64, device=eng.device)
+        lo, hi = self._grid_range(ng)
+        B = self.grid_block
+        for p0 in range(lo, hi, B):
+            p1 = min(p0 + B, hi)
+            c, w = coords[p0:p1], weights[p0:p1]
+            ao = eng.eval_ao(c, deriv=1 if gga else 0)
+            C = dm @ ao[0]
+            rho = eng.xc_rho(ao, C, deriv=1 if gga else 0)
+            e, wv = eng.xc_eval(terms, rho, w, gga)
+            nelec += torch.dot(w, rho[0])
+            exc += torch.dot(w, e)
+            aow = eng.xc_aow(ao, wv, gga)
+            vmat += ao[0] @ aow.T
+        vmat = vmat + vmat.T
+        return nelec, exc, vmat, hyb
+
+    def _grid_range(self, ng):
+        if self._nranks == 1:
+            return 0, ng
+        per = (ng + self._nranks - 1) // self._nranks
+        return min(self._rank * per, ng), min((self._rank + 1) * per, ng)
+
+    def _veff(self, dm):
+        nelec, exc, vxc, hyb = self.nr_rks(dm)
+        if self._nranks > 1:
+            import torch.distributed as dist
+            buf = torch.cat([vxc.reshape(-1), nelec.reshape(1), exc.reshape(1)])
+            dist.all_reduce(buf, group=self._pg)
+            n = vxc.shape[0]
+            vxc, nelec, exc = buf[:n * n].reshape(n, n), buf[n * n], buf[n * n + 1]
+        self._nelec_grid = nelec
+        if abs(hyb) > 1e-12:
+            J, K = self._jk(dm)
+            v = J - (0.5 * hyb) * K + vxc
+            e2 = 0.5 * torch.sum(dm * J) - (0.25 * hyb) * torch.sum(dm * K) + exc
+        else:
+            J, _ = self._jk(dm, with_k=False)
+            v = J + vxc
+            e2 = 0.5 * torch.sum(dm * J) + exc
+        return v, e2

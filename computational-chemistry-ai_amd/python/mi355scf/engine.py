@@ -58,6 +58,12 @@ def lib():
         L.mi_diis_errvec.argtypes = [vp, vp, vp, vp]
         L.mi_diis_combine.argtypes = [vp, vp, dp, ctypes.c_int, vp, vp]
         L.mi_diis_dots.argtypes = [vp, vp, vp, ctypes.c_int, dp, vp]
+        i64 = ctypes.c_int64
+        L.mi_grid_becke.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
+        L.mi_eval_ao.argtypes = [vp, vp, i64, ctypes.c_int, vp, vp]
+        L.mi_xc_rho.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
+        L.mi_xc_eval.argtypes = [ip, dp, ctypes.c_int, vp, vp, i64, ctypes.c_int, vp, vp, vp, vp, vp]
+        L.mi_xc_aow.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
         L.mi_c2s_table.argtypes = [ctypes.c_int, dp]
         L.mi_rys_roots_host.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp]
         _lib = L
@@ -173,6 +179,46 @@ class Engine:
         with torch.cuda.device(self.device):
             _check(lib().mi_time_jk_kernel(self._h, dm.data_ptr(), reps, ctypes.byref(ms), self._stream()))
         return ms.value
+
+    # --- rows a7-a9 (DFT) ------------------------------------------------------------------------
+    def becke_weights(self, coords, atom_of, vol, adjust):
+        w = torch.empty_like(vol)
+        _check(lib().mi_grid_becke(self._h, coords.data_ptr(), atom_of.data_ptr(), vol.data_ptr(), vol.numel(),
+                                   adjust.data_ptr(), w.data_ptr(), self._stream()))
+        return w
+
+    def eval_ao(self, coords, deriv=1, out=None):
+        ng = coords.shape[0]
+        if out is None:
+            out = self._new(4 if deriv else 1, self.nao, ng)
+        _check(lib().mi_eval_ao(self._h, coords.data_ptr(), ng, int(deriv), out.data_ptr(), self._stream()))
+        return out
+
+    def xc_rho(self, ao, C, deriv=1):
+        ng = ao.shape[-1]
+        rho = self._new(4 if deriv else 1, ng)
+        _check(lib().mi_xc_rho(self._h, ao.data_ptr(), C.data_ptr(), ng, int(deriv), rho.data_ptr(), self._stream()))
+        return rho
+
+    def xc_eval(self, terms, rho, weights, gga=True, want_raw=False):
+        """terms: [(coef, kind_id)] -> (exc[ng], wv[(1|4)][ng]) (+ vrho, vsigma if want_raw)."""
+        ng = rho.shape[-1]
+        kinds = np.array([k for _c, k in terms], dtype=np.int32)
+        coefs = np.array([c for c, _k in terms], dtype=np.float64)
+        exc = self._new(ng)
+        wv = self._new(4 if gga else 1, ng)
+        vr = self._new(ng) if want_raw else None
+        vs = self._new(ng) if want_raw else None
+        _check(lib().mi_xc_eval(kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dp(coefs), len(kinds),
+                                rho.data_ptr(), weights.data_ptr(), ng, int(gga), exc.data_ptr(), wv.data_ptr(),
+                                vr.data_ptr() if want_raw else None, vs.data_ptr() if want_raw else None, self._stream()))
+        return (exc, wv, vr, vs) if want_raw else (exc, wv)
+
+    def xc_aow(self, ao, wv, gga=True):
+        ng = ao.shape[-1]
+        aow = self._new(self.nao, ng)
+        _check(lib().mi_xc_aow(self._h, ao.data_ptr(), wv.data_ptr(), ng, int(gga), aow.data_ptr(), self._stream()))
+        return aow
 
     # --- row a10 -------------------------------------------------------------------------------
     def diis_errvec(self, sdf, out):

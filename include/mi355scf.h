@@ -90,6 +90,36 @@ int mi_diis_combine(mi_ctx *ctx, const double *d_hist, const double *coef, int n
 int mi_diis_dots(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int n, double *out,
                  void *stream);
 
+
+/* ---- DFT -------------------------------------------------------------- */
+
+/* Becke fuzzy-cell weights for `ng` atom-centred grid points: d_coords[ng][3] (Bohr), d_atom_of[ng]
+ * (owning atom), d_vol[ng] (radial x angular volume element), d_adjust[natm][natm] (Treutler radius
+ * adjustment a_ij, device) -> d_weights[ng].  Replaces libdft VXCgen_grid [MEM], reached from
+ * dft.RKS(mol) -> Grids.build (templates/calculate_energy.py:148,163; optimize_geometry.py:72,86). */
+int mi_grid_becke(mi_ctx *ctx, const double *d_coords, const int32_t *d_atom_of, const double *d_vol,
+                  int64_t ng, const double *d_adjust, double *d_weights, void *stream);
+
+/* AO values (deriv=0) or values+gradient (deriv=1) on grid points: d_ao[(1|4)][nao][ng].
+ * Replaces libdft GTOval_sph_deriv1 / gpu4pyscf GDFTeval_gto [MEM] (numint.eval_ao). */
+int mi_eval_ao(mi_ctx *ctx, const double *d_coords, int64_t ng, int deriv, double *d_ao, void *stream);
+
+/* rho and grad rho from d_C = D @ ao0 ([nao][ng]): d_rho[(1|4)][ng].  (numint.eval_rho [MEM]) */
+int mi_xc_rho(mi_ctx *ctx, const double *d_ao, const double *d_C, int64_t ng, int deriv, double *d_rho,
+              void *stream);
+
+/* Closed-shell XC energy density and potential on the grid.  kinds[]: 1 Slater, 2 B88, 3 VWN-RPA,
+ * 4 VWN5, 5 LYP, 6 PBE-x, 7 PBE-c with weights coefs[].  Outputs (any may be NULL): d_exc[ng] energy
+ * per volume; d_wv[(1|4)][ng] = {w*vrho/2, 2*w*vsigma*grad rho}; d_vrho, d_vsigma raw derivatives.
+ * Replaces libxc (HYB_GGA_XC_B3LYP etc.) reached through mf.xc (templates/calculate_energy.py:149). */
+int mi_xc_eval(const int32_t *kinds, const double *coefs, int nterms, const double *d_rho,
+               const double *d_w, int64_t ng, int gga, double *d_exc, double *d_wv, double *d_vrho,
+               double *d_vsigma, void *stream);
+
+/* d_aow[nao][ng] = sum_c d_ao[c] * d_wv[c]; Vxc = ao0 @ aow^T + transpose is then one DGEMM. */
+int mi_xc_aow(mi_ctx *ctx, const double *d_ao, const double *d_wv, int64_t ng, int gga, double *d_aow,
+              void *stream);
+
 /* Real-solid-harmonic coefficient table used by the kernels: out[ncart(l)][2l+1] (host). */
 int mi_c2s_table(int l, double *out);
 

@@ -1,0 +1,335 @@
+"""CPU oracle for the DFT half of the hot path.  TEST INFRASTRUCTURE.
+
+PARITY UNPINNED against PySCF/libxc (absent here).  Restates, in plain numpy:
+  * atom-centred grids the way `pyscf.dft.gen_grid.Grids.build` is documented to build them [MEM]:
+    Treutler-Ahlrichs M4 radial quadrature, Lebedev spheres (scipy.integrate.lebedev_rule), NWChem-style
+    pruning, Becke fuzzy cells (3x iterated polynomial) with Treutler's sqrt(Bragg radius) adjustment;
+  * AO values and gradients on the grid;
+  * the closed-shell energy densities of Slater, VWN-RPA, VWN5, B88, LYP, PBE (spin-resolved textbook
+    forms evaluated at rho_a = rho_b), with d/drho and d/dsigma from the COMPLEX-STEP derivative -- a
+    different technique from the forward-mode dual numbers of the HIP kernel, so the two cross-check;
+  * `nr_rks`: (N_elec, E_xc, V_xc) like `numint.nr_rks` [MEM], reached in the reference through
+    `mf.xc = 'B3LYP'` (templates/calculate_energy.py:149; templates/optimize_geometry.py:73).
+B3LYP = 0.2 HF + 0.08 Slater + 0.72 B88 + 0.19 VWN-RPA + 0.81 LYP (libxc HYB_GGA_XC_B3LYP) [MEM].
+"""
+import ctypes
+
+import numpy as np
+
+from . import oracle as orc
+
+BOHR = 0.52917721092
+_BRAGG = {1: 0.35, 2: 1.40, 3: 1.45, 4: 1.05, 5: 0.85, 6: 0.70, 7: 0.65, 8: 0.60, 9: 0.50, 10: 1.50,
+          11: 1.80, 12: 1.50, 13: 1.25, 14: 1.10, 15: 1.00, 16: 1.00, 17: 1.00, 18: 1.80}
+_TA_XI = {1: 0.8, 2: 0.9, 3: 1.8, 4: 1.4, 5: 1.3, 6: 1.1, 7: 0.9, 8: 0.9, 9: 0.9, 10: 0.9,
+          11: 1.4, 12: 1.3, 13: 1.3, 14: 1.2, 15: 1.1, 16: 1.0, 17: 1.0, 18: 1.0}
+_RAD = [(10, 15, 20), (30, 40, 50), (40, 60, 65), (50, 75, 80), (60, 90, 95), (70, 105, 110)]
+_ANG = [(50, 86, 110), (110, 194, 194), (194, 302, 302), (302, 302, 434), (434, 590, 590), (590, 770, 770)]
+_LEB_NGRID = [1, 6, 14, 26, 38, 50, 74, 86, 110, 146, 170, 194, 230, 266, 302, 350, 434, 590, 770, 974]
+_LEB_DEGREE = {6: 3, 14: 5, 26: 7, 38: 9, 50: 11, 74: 13, 86: 15, 110: 17, 146: 19, 170: 21, 194: 23, 230: 25,
+               266: 27, 302: 29, 350: 31, 434: 35, 590: 41, 770: 47, 974: 53}
+
+
+def _period(z):
+    return 0 if z <= 2 else (1 if z <= 10 else 2)
+
+
+def lebedev(n):
+    from scipy.integrate import lebedev_rule
+    x, w = lebedev_rule(_LEB_DEGREE[n])
+    assert x.shape[1] == n
+    return x.T.copy(), w / (4 * np.pi)
+
+
+def treutler_ahlrichs(n, z):
+    xi = _TA_XI[z]
+    i = np.arange(1, n + 1)
+    step = np.pi / (n + 1)
+    x = np.cos(i * step)
+    ln2 = xi / np.log(2)
+    r = -ln2 * (1 + x) ** 0.6 * np.log((1 - x) / 2)
+    dr = step * np.sin(i * step) * ln2 * (1 + x) ** 0.6 * (-0.6 / (1 + x) * np.log((1 - x) / 2) + 1 / (1 - x))
+    return r[::-1].copy(), dr[::-1].copy()
+
+
+def nwchem_prune(z, rads, n_ang):
+    alphas = np.array(((0.25, 0.5, 1.0, 4.5), (0.1667, 0.5, 0.9, 3.5), (0.1, 0.4, 0.8, 2.5)))
+    leb = np.array(_LEB_NGRID[4:])
+    if n_ang < 50:
+        return np.repeat(n_ang, len(rads))
+    if n_ang == 50:
+        leb_l = np.array([1, 2, 2, 2, 1])
+    else:
+        idx = int(np.where(leb == n_ang)[0][0])
+        leb_l = np.array([1, 3, idx - 1, idx, idx - 1])
+    r_atom = _BRAGG[z] / BOHR + 1e-200
+    row = 0 if z <= 2 else (1 if z <= 10 else 2)
+    place = ((rads / r_atom).reshape(-1, 1) > alphas[row]).sum(axis=1)
+    return leb[leb_l[place]]
+
+
+def build_grids(mol, level=3):
+    coords_all, w_all = [], []
+    zs = mol.atom_charges()
+    R = mol.atom_coords()
+    natm = mol.natm
+    rad = np.sqrt(np.array([_BRAGG[int(z)] / BOHR for z in zs]))
+    rr = rad[:, None] / rad[None, :]
+    a = 0.25 * (rr.T - rr)
+    a = np.clip(a, -0.5, 0.5)
+    dist = np.linalg.norm(R[:, None] - R[None, :], axis=2)
+    for ia in range(natm):
+        z = int(zs[ia])
+        n_rad, n_ang = _RAD[level][_period(z)], _ANG[level][_period(z)]
+        r, dr = treutler_ahlrichs(n_rad, z)
+        rw = 4 * np.pi * r * r * dr
+        angs = nwchem_prune(z, r, n_ang)
+        cs, ws = [], []
+        for n in sorted(set(angs.tolist())):
+            x, w = lebedev(n)
+            idx = np.where(angs == n)[0]
+            cs.append(np.einsum("i,jk->jik", r[idx], x).reshape(-1, 3))
+            ws.append(np.einsum("i,j->ji", rw[idx], w).ravel())
+        c = np.vstack(cs) + R[ia]
+        vol = np.hstack(ws)
+        gd = np.linalg.norm(c[None, :, :] - R[:, None, :], axis=2)  # [natm, ng]
+        pb = np.ones((natm, len(c)))
+        for i in range(natm):
+            for j in range(i):
+                g = (gd[i] - gd[j]) / dist[i, j]
+                g = g + a[i, j] * (1 - g * g)
+                for _ in range(3):
+                    g = (3 - g * g) * g * 0.5
+                pb[i] *= 0.5 * (1 - g)
+                pb[j] *= 0.5 * (1 + g)
+        coords_all.append(c)
+        w_all.append(vol * pb[ia] / pb.sum(axis=0))
+    return np.vstack(coords_all), np.hstack(w_all)
+
+
+# ---------------------------------------------------------------------------------------------
+def _c2s(l):
+    out = np.zeros((10, 7))
+    orc.lib().orc_c2s.restype = None
+    orc.lib().orc_c2s(ctypes.c_int(l), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return out[:(l + 1) * (l + 2) // 2, :2 * l + 1]
+
+
+def eval_ao(mol, coords, deriv=1):
+    """ao[4 or 1][ng][nao]: values and d/dx, d/dy, d/dz of the real-spherical contracted AOs."""
+    ng = len(coords)
+    nao = mol.nao
+    out = np.zeros((4 if deriv else 1, ng, nao))
+    loc = mol.ao_loc_nr()
+    for ish in range(mol.nbas):
+        ia, l, npr, _, _, pe, pc, _ = mol._bas[ish]
+        exps, cs = mol._env[pe:pe + npr], mol._env[pc:pc + npr]
+        d = coords - mol._env[mol._atm[ia, 1]:mol._atm[ia, 1] + 3]
+        r2 = (d * d).sum(axis=1)
+        e = np.exp(-np.outer(r2, exps))
+        rad = e @ cs
+        drad = e @ (-2.0 * exps * cs)
+        c2s = _c2s(l)
+        x, y, z = d.T
+        k = 0
+        poly = np.zeros((ng, c2s.shape[0]))
+        dpoly = np.zeros((3, ng, c2s.shape[0]))
+        for lx in range(l, -1, -1):
+            for ly in range(l - lx, -1, -1):
+                lz = l - lx - ly
+                poly[:, k] = x ** lx * y ** ly * z ** lz
+                if lx:
+                    dpoly[0, :, k] = lx * x ** (lx - 1) * y ** ly * z ** lz
+                if ly:
+                    dpoly[1, :, k] = ly * x ** lx * y ** (ly - 1) * z ** lz
+                if lz:
+                    dpoly[2, :, k] = lz * x ** lx * y ** ly * z ** (lz - 1)
+                k += 1
+        s = poly @ c2s
+        sl = slice(loc[ish], loc[ish + 1])
+        out[0][:, sl] = rad[:, None] * s
+        if deriv:
+            for c in range(3):
+                out[1 + c][:, sl] = (drad * d[:, c])[:, None] * s + rad[:, None] * (dpoly[c] @ c2s)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Energy densities per volume, spin-resolved textbook forms; complex-safe (no abs / max).
+# ---------------------------------------------------------------------------------------------
+def _slater(ra, rb):
+    cx = 1.5 * (3.0 / (4 * np.pi)) ** (1.0 / 3)
+    return -cx * (ra ** (4.0 / 3) + rb ** (4.0 / 3))
+
+
+def _b88(ra, rb, saa, sbb):
+    beta = 0.0042
+
+    def one(r, s):
+        x = np.sqrt(s) / r ** (4.0 / 3)
+        asinh = np.log(x + np.sqrt(x * x + 1))
+        return -beta * r ** (4.0 / 3) * x * x / (1 + 6 * beta * x * asinh)
+    return _slater(ra, rb) + one(ra, saa) + one(rb, sbb)
+
+
+def _vwn(r, A, x0, b, c):
+    rs = (3.0 / (4 * np.pi * r)) ** (1.0 / 3)
+    x = np.sqrt(rs)
+    X = x * x + b * x + c
+    X0 = x0 * x0 + b * x0 + c
+    Q = np.sqrt(4 * c - b * b)
+    at = np.arctan(Q / (2 * x + b))  # numpy's complex arctan keeps the O(h) imaginary part (complex step)
+    eps = A * (np.log(x * x / X) + 2 * b / Q * at
+               - b * x0 / X0 * (np.log((x - x0) ** 2 / X) + 2 * (b + 2 * x0) / Q * at))
+    return r * eps
+
+
+def _vwn_rpa(r):
+    return _vwn(r, 0.0310907, -0.409286, 13.0720, 42.7198)
+
+
+def _vwn5(r):
+    return _vwn(r, 0.0310907, -0.10498, 3.72744, 12.9352)
+
+
+def _lyp(ra, rb, saa, sab, sbb):
+    a, b, c, d = 0.04918, 0.132, 0.2533, 0.349
+    r = ra + rb
+    s = saa + 2 * sab + sbb
+    t = r ** (-1.0 / 3)
+    D = 1 + d * t
+    w = np.exp(-c * t) / D * r ** (-11.0 / 3)
+    dl = c * t + d * t / D
+    cf = 0.3 * (3 * np.pi ** 2) ** (2.0 / 3)
+    t1 = -4 * a / D * ra * rb / r
+    br = ra * rb * (2 ** (11.0 / 3) * cf * (ra ** (8.0 / 3) + rb ** (8.0 / 3)) + (47.0 / 18 - 7 * dl / 18) * s
+                    - (2.5 - dl / 18) * (saa + sbb) - (dl - 11) / 9 * (ra / r * saa + rb / r * sbb))
+    br = br - 2.0 / 3 * r * r * s + (2.0 / 3 * r * r - ra * ra) * sbb + (2.0 / 3 * r * r - rb * rb) * saa
+    return t1 - a * b * w * br
+
+
+def _pw92_mod(rs):
+    A, a1, b1, b2, b3, b4 = 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294
+    A = 0.031090690869654895  # PW_MOD, as libxc's GGA_C_PBE uses [MEM]
+    x = np.sqrt(rs)
+    return -2 * A * (1 + a1 * rs) * np.log(1 + 1 / (2 * A * (b1 * x + b2 * rs + b3 * rs * x + b4 * rs * rs)))
+
+
+def _pbe_x(r, s):
+    kappa, mu = 0.804, 0.06672455060314922 * np.pi ** 2 / 3
+    kf = (3 * np.pi ** 2 * r) ** (1.0 / 3)
+    s2 = s / (4 * kf * kf * r * r)
+    ex = -0.75 * (3 / np.pi) ** (1.0 / 3) * r ** (4.0 / 3)
+    return ex * (1 + kappa - kappa / (1 + mu * s2 / kappa))
+
+
+def _pbe_c(r, s):
+    beta, gamma = 0.06672455060314922, (1 - np.log(2)) / np.pi ** 2
+    rs = (3.0 / (4 * np.pi * r)) ** (1.0 / 3)
+    ec = _pw92_mod(rs)
+    kf = (3 * np.pi ** 2 * r) ** (1.0 / 3)
+    ks2 = 4 * kf / np.pi
+    t2 = s / (4 * ks2 * r * r)
+    Aa = beta / gamma / (np.exp(-ec / gamma) - 1)
+    H = gamma * np.log(1 + beta / gamma * t2 * (1 + Aa * t2) / (1 + Aa * t2 + Aa * Aa * t2 * t2))
+    return r * (ec + H)
+
+
+def parse_xc(name):
+    """-> (hyb, [(coef, kind)])."""
+    key = str(name).upper().replace("-", "").replace("_", "").replace(" ", "")
+    if key in ("HF", ""):
+        return 1.0, []
+    if key == "B3LYP":
+        return 0.2, [(0.08, "slater"), (0.72, "b88"), (0.19, "vwn_rpa"), (0.81, "lyp")]
+    if key == "PBE":
+        return 0.0, [(1.0, "pbe_x"), (1.0, "pbe_c")]
+    if key in ("LDA", "LDA,VWN", "SVWN", "LDA,VWN5", "SVWN5"):
+        return 0.0, [(1.0, "slater"), (1.0, "vwn5")]
+    if key in ("BLYP", "B88,LYP"):
+        return 0.0, [(1.0, "b88"), (1.0, "lyp")]
+    if key == "PBE0":
+        return 0.25, [(0.75, "pbe_x"), (1.0, "pbe_c")]
+    raise NotImplementedError(f"xc functional '{name}' is not implemented in the oracle")
+
+
+def energy_density(terms, rho, sigma):
+    """Closed-shell e(rho, sigma) per volume; works on complex arguments."""
+    ra = rb = rho * 0.5
+    s4 = sigma * 0.25
+    e = 0.0
+    for coef, kind in terms:
+        if kind == "slater":
+            e = e + coef * _slater(ra, rb)
+        elif kind == "b88":
+            e = e + coef * _b88(ra, rb, s4, s4)
+        elif kind == "vwn_rpa":
+            e = e + coef * _vwn_rpa(rho)
+        elif kind == "vwn5":
+            e = e + coef * _vwn5(rho)
+        elif kind == "lyp":
+            e = e + coef * _lyp(ra, rb, s4, s4, s4)
+        elif kind == "pbe_x":
+            e = e + coef * _pbe_x(rho, sigma)
+        elif kind == "pbe_c":
+            e = e + coef * _pbe_c(rho, sigma)
+        else:
+            raise KeyError(kind)
+    return e
+
+
+def eval_xc(terms, rho, sigma):
+    """-> (e per volume, de/drho, de/dsigma) with complex-step derivatives."""
+    h = 1e-30
+    e = energy_density(terms, rho, sigma)
+    vr = np.imag(energy_density(terms, rho + 1j * h, sigma + 0j)) / h
+    vs = np.imag(energy_density(terms, rho + 0j, sigma + 1j * h)) / h
+    return np.real(e), vr, vs
+
+
+def nr_rks(mol, coords, weights, xc, dm, block=20000, rho_cut=1e-10):
+    hyb, terms = parse_xc(xc)
+    nao = mol.nao
+    nelec = exc = 0.0
+    vmat = np.zeros((nao, nao))
+    for p0 in range(0, len(coords), block):
+        c, w = coords[p0:p0 + block], weights[p0:p0 + block]
+        ao = eval_ao(mol, c, 1)
+        c0 = ao[0] @ dm
+        rho = np.einsum("gi,gi->g", ao[0], c0)
+        grad = np.array([2 * np.einsum("gi,gi->g", ao[1 + k], c0) for k in range(3)])
+        sigma = (grad * grad).sum(axis=0)
+        ok = rho > rho_cut
+        rr = np.where(ok, rho, 1.0)
+        ss = np.where(ok, sigma, 0.0)
+        e, vr, vs = eval_xc(terms, rr, ss)
+        e, vr, vs = np.where(ok, e, 0), np.where(ok, vr, 0), np.where(ok, vs, 0)
+        nelec += float(w @ rho)
+        exc += float(w @ e)
+        aow = ao[0] * (0.5 * w * vr)[:, None]
+        for k in range(3):
+            aow += ao[1 + k] * (2 * w * vs * grad[k])[:, None]
+        vmat += ao[0].T @ aow
+    return nelec, exc, vmat + vmat.T, hyb
+
+
+def rks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-9, max_cycle=50, verbose=False):
+    coords, weights = build_grids(mol, level)
+    o = orc.Oracle(mol)
+    info = {}
+
+    def veff(dm):
+        n, exc, vxc, hyb = nr_rks(mol, coords, weights, xc, dm)
+        J, K = o.jk(dm)
+        info["nelec"] = n
+        v = J + vxc
+        e2 = 0.5 * float(np.sum(dm * J)) + exc
+        if hyb:
+            v = v - 0.5 * hyb * K
+            e2 -= 0.25 * hyb * float(np.sum(dm * K))
+        return v, e2
+
+    r = orc.rhf(mol, dm0=dm0, conv_tol=conv_tol, max_cycle=max_cycle, veff_fn=veff, verbose=verbose)
+    r["nelec_grid"] = info.get("nelec")
+    r["ngrids"] = len(weights)
+    return r

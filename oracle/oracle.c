@@ -650,3 +650,11 @@ int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* c2s table for tests and the numpy AO evaluator: out[10][7] */
+void orc_c2s(int l, double *out)
+{
+    double c[NCART_MAX][NSPH_MAX];
+    c2s_matrix(l, c);
+    memcpy(out, c, sizeof(c));
+}
