@@ -94,19 +94,16 @@ class RKS(RHF):
         return nelec, exc, vmat, hyb
 
     def _grid_range(self, ng):
-        if self._nranks == 1:
-            return 0, ng
-        per = (ng + self._nranks - 1) // self._nranks
-        return min(self._rank * per, ng), min((self._rank + 1) * per, ng)
+        from . import parallel
+        return parallel.split_range(ng, self._rank, self._nranks)
 
     def _veff(self, dm):
         nelec, exc, vxc, hyb = self.nr_rks(dm)
         if self._nranks > 1:
-            import torch.distributed as dist
-            buf = torch.cat([vxc.reshape(-1), nelec.reshape(1), exc.reshape(1)])
-            dist.all_reduce(buf, group=self._pg)
-            n = vxc.shape[0]
-            vxc, nelec, exc = buf[:n * n].reshape(n, n), buf[n * n], buf[n * n + 1]
+            from . import parallel
+            nelec, exc = nelec.reshape(1), exc.reshape(1)
+            parallel.all_reduce_fused([vxc, nelec, exc], self._pg)
+            nelec, exc = nelec[0], exc[0]
         self._nelec_grid = nelec
         if abs(hyb) > 1e-12:
             J, K = self._jk(dm)

@@ -1,0 +1,61 @@
+"""Multi-GPU plumbing: one process per GPU, `torch.distributed` over RCCL/xGMI.
+
+The resident-ERI tile runs are dealt round-robin to ranks inside `mi_eri_prepare(rank, nranks)` -- no
+ERI ever crosses xGMI.  Each Fock build ends in ONE all-reduce of a fused FP64 buffer ([J|K], or
+[Vxc|N_elec|E_xc] for the grid-sharded XC part); D is replicated, diagonalisation/DIIS are replicated.
+With the `gloo` backend (CPU tests; or two ranks sharing one GPU) tensors are staged through host memory.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None, device=None):
+    """Initialise the default process group from torchrun-style env vars; returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def all_reduce_sum(t, group=None):
+    """In-place sum over ranks of a (device or host) tensor; returns it."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    backend = dist.get_backend(group)
+    if backend == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def all_reduce_fused(tensors, group=None):
+    """One collective for several tensors (fused buffer), results written back in place."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return tensors
+    flat = torch.cat([x.reshape(-1) for x in tensors])
+    all_reduce_sum(flat, group)
+    off = 0
+    for x in tensors:
+        n = x.numel()
+        x.copy_(flat[off:off + n].view_as(x))
+        off += n
+    return tensors
+
+
+def split_range(n, rank, nranks):
+    """Contiguous, exhaustive, non-overlapping split of range(n)."""
+    per = (n + nranks - 1) // nranks
+    return min(rank * per, n), min((rank + 1) * per, n)

@@ -161,13 +161,8 @@ class SCF:
     def _jk(self, dm, with_j=True, with_k=True):
         J, K = self.engine.get_jk(dm, with_j, with_k)
         if self._nranks > 1:
-            import torch.distributed as dist
-            if with_j and with_k:
-                buf = torch.stack([J, K])
-                dist.all_reduce(buf, group=self._pg)
-                J, K = buf[0], buf[1]
-            else:
-                dist.all_reduce(J if with_j else K, group=self._pg)
+            from . import parallel
+            parallel.all_reduce_fused([x for x in (J, K) if x is not None], self._pg)
         return J, K
 
     def get_jk(self, mol=None, dm=None, hermi=1, with_j=True, with_k=True, **kw):

@@ -1,0 +1,68 @@
+"""world_size-2 gloo tests (CPU, no GPU) of the multi-rank plumbing the sharded Fock build uses:
+fused all-reduce of partial [J|K] (partials produced here by the CPU oracle on disjoint density
+shards -- J and K are linear in D) and the grid split."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, MOLECULES
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "computational-chemistry-ai_amd", "python"))
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      OMP_NUM_THREADS="2")
+    from mi355scf import parallel
+    from mi355scf.mole import Mole
+    from oracle import oracle as orc
+    r, w = parallel.init("gloo")
+    assert (r, w) == (rank, world)
+    mol = Mole(atom=MOLECULES["h2o"], basis="6-31g", verbose=0).build()
+    rng = np.random.default_rng(11)
+    a = rng.normal(size=(mol.nao, mol.nao))
+    D = a + a.T
+    # shard the density by row blocks: D = sum_r D_r ; J(D) = sum_r J(D_r)
+    lo, hi = parallel.split_range(mol.nao, rank, world)
+    Dr = np.zeros_like(D)
+    Dr[lo:hi] = D[lo:hi]
+    Dr = 0.5 * (Dr + Dr.T)
+    o = orc.Oracle(mol)
+    Jr, Kr = o.jk(Dr)
+    J, K = torch.from_numpy(Jr.copy()), torch.from_numpy(Kr.copy())
+    parallel.all_reduce_fused([J, K])
+    Jf, Kf = o.jk(D)
+    ok = np.abs(J.numpy() - Jf).max() < 1e-10 and np.abs(K.numpy() - Kf).max() < 1e-10
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    parallel.all_reduce_sum(t)
+    ok = ok and float(t) == world * (world + 1) / 2
+    q.put((rank, bool(ok)))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_fused_allreduce_of_partial_jk_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_split_range_is_exhaustive_and_disjoint():
+    from mi355scf.parallel import split_range
+    for n in (0, 1, 7, 64, 1001):
+        for w in (1, 2, 3, 8):
+            seen = []
+            for r in range(w):
+                lo, hi = split_range(n, r, w)
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
