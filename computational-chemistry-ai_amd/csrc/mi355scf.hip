@@ -225,6 +225,10 @@ struct mi_ctx {
     double *d_red = nullptr;
     mi_eri_stats stats{};
     bool eri_ready = false;
+    // tunables (mi_set_option)
+    int opt_runmax = 8;      // tiles per run
+    int opt_jk_variant = 1;  // 0: simple kernel, 1: software-pipelined kernel
+    int opt_jk_noatomic = 0; // timing experiments only: skip the atomic adds (results are wrong)
 };
 
 static inline int pc_index(int la, int lb) { return la * (la + 1) / 2 + lb; }
@@ -336,6 +340,17 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
 }
 
 extern "C" int mi_ctx_nao(const mi_ctx *c) { return c ? c->nao : -1; }
+
+extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
+{
+    if (!c || !key) return fail("mi_set_option: null argument");
+    std::string k(key);
+    if (k == "runmax") c->opt_runmax = (int)value;           // takes effect at the next mi_eri_prepare
+    else if (k == "jk_variant") c->opt_jk_variant = (int)value;
+    else if (k == "jk_noatomic") c->opt_jk_noatomic = (int)value;
+    else return fail("mi_set_option: unknown key '%s'", key);
+    return 0;
+}
 
 // =================================================================================================
 // One-electron integrals: one thread per shell pair (i >= j)
@@ -940,7 +955,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     }
 
     // ---- 4. tiles and runs.  Run = tiles sharing (J,K,L), ordered by I; long runs are split.
-    const int RUNMAX = 8;
+    const int RUNMAX = std::max(1, c->opt_runmax);
     std::vector<int> bpI(nbp), bpJ(nbp);
     for (int I = 0, n = 0; I < nblk; I++)
         for (int J = 0; J <= I; J++, n++) { bpI[n] = I; bpJ[n] = J; }
@@ -969,7 +984,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                     c->tiles.push_back({I, J, K, L});
                     c->tile_off.push_back(off);
                     int bi = bsize(I), bj = bsize(J), bk = bsize(K), bl = bsize(L);
-                    off += (int64_t)bj * 4 * bi * bk * 2;
+                    off += (int64_t)BLK * 4 * bi * bk * 2; // j is always padded to 8 rows (J==last implies I==last: rare)
                     int64_t nij = (I > J) ? (int64_t)bi * bj : (int64_t)bi * (bi + 1) / 2;
                     int64_t nkl = (K > L) ? (int64_t)bk * bl : (int64_t)bk * (bk + 1) / 2;
                     nuniq += (ij > kl) ? nij * nkl : nij * (nij + 1) / 2;
@@ -1126,7 +1141,7 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
     const int i = lane >> 3, k = lane & 7;
     const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
     const int ld = A.ld;
-    const int bj = min(BLK, A.nao - J0), bk = min(BLK, A.nao - K0);
+    const int bj = BLK, bk = min(BLK, A.nao - K0); // tiles are padded to 8 j-rows
     const double *__restrict__ D = A.D;
 
     // run-invariant density rows
@@ -1218,6 +1233,141 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
     }
 }
 
+
+// Software-pipelined variant.  Tiles always hold 8 j-rows (zero padded); lanes outside a short (i,k)
+// block read a clamped in-range chunk: their products meet zero rows/columns of the padded density or
+// land in padded accumulator cells, so no masking is needed.  A ring of 4 row buffers keeps three rows
+// (12 KB per wave) plus the next tile's density rows in flight while the current row is digested.
+template <bool WITH_J, bool WITH_K, bool ATOMICS>
+__global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
+{
+    const int lane = threadIdx.x;
+    const int run_id = blockIdx.x;
+    if (run_id >= A.nruns) return;
+    const RunRec R = A.runs[run_id];
+    const int i = lane >> 3, k = lane & 7;
+    const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
+    const int ld = A.ld;
+    const int bk = min(BLK, A.nao - K0);
+    const int kc = min(k, bk - 1);
+    const double *__restrict__ D = A.D;
+
+    double dKL[8], dJK[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) dKL[l] = D[(size_t)(K0 + k) * ld + L0 + l];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dJK[j] = D[(size_t)(J0 + j) * ld + K0 + k];
+    double kjl[8][8], jkl[8], kjk[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        jkl[j] = 0.0; kjk[j] = 0.0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) kjl[j][l] = 0.0;
+    }
+
+    // ---- prologue: tile 0 descriptors, density rows and the first 4 tile rows
+    int I0 = A.tile_I[R.first] * BLK;
+    int bi = min(BLK, A.nao - I0);
+    const double2 *__restrict__ T = reinterpret_cast<const double2 *>(A.tiles + A.tile_off[R.first]) + (min(i, bi - 1) * bk + kc);
+    int cs = bi * bk;
+    double dIJ[8], dIL[8], dIK;
+#pragma unroll
+    for (int j = 0; j < 8; j++) dIJ[j] = D[(size_t)(I0 + i) * ld + J0 + j];
+#pragma unroll
+    for (int l = 0; l < 8; l++) dIL[l] = D[(size_t)(I0 + i) * ld + L0 + l];
+    dIK = D[(size_t)(I0 + i) * ld + K0 + k];
+    double2 ring[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int lp = 0; lp < 4; lp++) ring[r][lp] = T[(size_t)(r * 4 + lp) * cs];
+
+    for (int t = 0; t < R.count; t++) {
+        const bool has_next = (t + 1 < R.count);
+        const int tn = R.first + (has_next ? t + 1 : t);
+        // next tile: descriptors and density rows (issued early, consumed after this tile)
+        const int I0n = A.tile_I[tn] * BLK;
+        const int bin = min(BLK, A.nao - I0n);
+        const double2 *__restrict__ Tn = reinterpret_cast<const double2 *>(A.tiles + A.tile_off[tn]) + (min(i, bin - 1) * bk + kc);
+        const int csn = bin * bk;
+        double dIJn[8], dILn[8], dIKn;
+#pragma unroll
+        for (int j = 0; j < 8; j++) dIJn[j] = D[(size_t)(I0n + i) * ld + J0 + j];
+#pragma unroll
+        for (int l = 0; l < 8; l++) dILn[l] = D[(size_t)(I0n + i) * ld + L0 + l];
+        dIKn = D[(size_t)(I0n + i) * ld + K0 + k];
+
+        double kik = 0.0, jij[8], kil[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { jij[j] = 0.0; kil[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            double v[8];
+#pragma unroll
+            for (int lp = 0; lp < 4; lp++) { v[2 * lp] = ring[j & 3][lp].x; v[2 * lp + 1] = ring[j & 3][lp].y; }
+            // refill this ring slot: row j+4 of this tile, or row j-4 of the next tile
+            if (j < 4) {
+#pragma unroll
+                for (int lp = 0; lp < 4; lp++) ring[j & 3][lp] = T[(size_t)((j + 4) * 4 + lp) * cs];
+            } else if (has_next) {
+#pragma unroll
+                for (int lp = 0; lp < 4; lp++) ring[j & 3][lp] = Tn[(size_t)((j - 4) * 4 + lp) * csn];
+            }
+            const double *__restrict__ dJL = D + (size_t)(J0 + j) * ld + L0; // wave-uniform row
+#pragma unroll
+            for (int l = 0; l < 8; l++) {
+                const double x = v[l];
+                if (WITH_K) {
+                    kik = fma(x, dJL[l], kik);
+                    kil[l] = fma(x, dJK[j], kil[l]);
+                    kjl[j][l] = fma(x, dIK, kjl[j][l]);
+                    kjk[j] = fma(x, dIL[l], kjk[j]);
+                }
+                if (WITH_J) {
+                    jij[j] = fma(x, dKL[l], jij[j]);
+                    jkl[l] = fma(x, dIJ[j], jkl[l]);
+                }
+            }
+        }
+        if (WITH_K) {
+            double r = reduce8(kil, lane, 4, 2, 1);
+            if (ATOMICS) {
+                atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik);
+                atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + L0 + k], r);
+            } else if (r + kik == 1.2345e300) A.Kacc[0] = r;
+        }
+        if (WITH_J) {
+            double r = reduce8(jij, lane, 4, 2, 1);
+            if (ATOMICS) atomicAdd(&A.Jacc[(size_t)(I0 + i) * ld + J0 + k], r);
+            else if (r == 1.2345e300) A.Jacc[0] = r;
+        }
+        I0 = I0n; T = Tn; cs = csn; dIK = dIKn;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { dIJ[j] = dIJn[j]; dIL[j] = dILn[j]; }
+    }
+    if (WITH_J) {
+        double r = reduce8(jkl, lane, 32, 16, 8);
+        if (ATOMICS) atomicAdd(&A.Jacc[(size_t)(K0 + k) * ld + L0 + i], r);
+        else if (r == 1.2345e300) A.Jacc[0] = r;
+    }
+    if (WITH_K) {
+        double r = reduce8(kjk, lane, 32, 16, 8);
+        double s[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            double col[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) col[j] = kjl[j][l];
+            s[l] = reduce8(col, lane, 32, 16, 8);
+        }
+        double r2 = reduce8(s, lane, 4, 2, 1);
+        if (ATOMICS) {
+            atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + K0 + k], r);
+            atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + L0 + k], r2);
+        } else if (r + r2 == 1.2345e300) A.Kacc[0] = r;
+    }
+}
+
 __global__ void pad_density_kernel(const double *D, double *Dp, int nao, int ld)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1240,6 +1390,14 @@ static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
     JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_runs, (int)c->runs.size(), c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao};
     if (A.nruns == 0) return 0;
     dim3 g(A.nruns), b(64);
+    if (c->opt_jk_variant == 1) {
+        if (c->opt_jk_noatomic) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, true, false>), g, b, 0, st, A);
+        else if (wj && wk) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, true, true>), g, b, 0, st, A);
+        else if (wj) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, false, true>), g, b, 0, st, A);
+        else hipLaunchKernelGGL((jk_tiles_pipe_kernel<false, true, true>), g, b, 0, st, A);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (wj && wk) hipLaunchKernelGGL((jk_tiles_kernel<true, true>), g, b, 0, st, A);
     else if (wj) hipLaunchKernelGGL((jk_tiles_kernel<true, false>), g, b, 0, st, A);
     else hipLaunchKernelGGL((jk_tiles_kernel<false, true>), g, b, 0, st, A);

@@ -50,6 +50,7 @@ def lib():
         L.mi_ctx_destroy.argtypes = [vp]
         L.mi_ctx_destroy.restype = None
         L.mi_ctx_nao.argtypes = [vp]
+        L.mi_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
         L.mi_int1e.argtypes = [vp, vp, vp, vp, vp, dp, vp]
         L.mi_eri_prepare.argtypes = [vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp]
         L.mi_eri_get_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
@@ -125,6 +126,9 @@ class Engine:
             pass
 
     close = __del__
+
+    def set_option(self, key, value):
+        _check(lib().mi_set_option(self._h, key.encode(), float(value)))
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

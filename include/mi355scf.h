@@ -41,6 +41,11 @@ int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, int nbas, co
 void mi_ctx_destroy(mi_ctx *ctx);
 int mi_ctx_nao(const mi_ctx *ctx);
 
+/* Tunables (project-defined, no reference counterpart): "runmax" tiles per run (before
+ * mi_eri_prepare), "jk_variant" 0 simple / 1 software-pipelined J/K kernel, "jk_noatomic" 1 = timing
+ * experiment without the atomic adds (results invalid). */
+int mi_set_option(mi_ctx *ctx, const char *key, double value);
+
 /* One-electron integrals into device buffers (any of them may be NULL): overlap S, kinetic T, nuclear
  * attraction V, dipole d_dip[3][nao][nao] about `origin` (host double[3], NULL = zero).
  * Replaces: libcint int1e_ovlp_sph / int1e_kin_sph / int1e_nuc_sph / int1e_r_sph [MEM], reached from
