@@ -217,6 +217,9 @@ struct mi_ctx {
     int64_t *d_tile_off = nullptr;
     int *d_tile_I = nullptr;
     RunRec *d_runs = nullptr;
+    RunRec *d_segs = nullptr;            // runs cut at wave boundaries
+    int *d_wave_seg = nullptr;           // [nwaves+1] segment range of each wave
+    int n_jk_waves = 0;
     double *d_tiles = nullptr;
     int64_t tile_doubles = 0;
     // J/K work buffers
@@ -226,9 +229,9 @@ struct mi_ctx {
     mi_eri_stats stats{};
     bool eri_ready = false;
     // tunables (mi_set_option)
-    int opt_runmax = 8;      // tiles per run
-    int opt_jk_variant = 1;  // 0: simple kernel, 1: software-pipelined kernel
-    int opt_jk_noatomic = 0; // timing experiments only: skip the atomic adds (results are wrong)
+    int opt_runmax = 0;      // tiles per J/K work item (0 = auto: ntiles/2048 clamped to [8,64])
+    int opt_jk_waves = 0;    // 0: one wave per work item, longest first; >0: that many waves, equal-cost shares
+    int opt_jk_nt = 1;       // nontemporal loads for the tile stream
 };
 
 static inline int pc_index(int la, int lb) { return la * (la + 1) / 2 + lb; }
@@ -321,10 +324,10 @@ static void free_eri(mi_ctx *c)
         c->pc[i].d_recs = nullptr; c->pc[i].d_q = nullptr;
         c->pc[i].recs.clear(); c->pc[i].q.clear();
     }
-    void *ptrs[] = {c->d_prim, c->d_M, c->d_tile_table, c->d_tile_off, c->d_tile_I, c->d_runs, c->d_tiles};
+    void *ptrs[] = {c->d_prim, c->d_M, c->d_tile_table, c->d_tile_off, c->d_tile_I, c->d_runs, c->d_tiles, c->d_segs, c->d_wave_seg};
     for (void *p : ptrs) if (p) hipFree(p);
     c->d_prim = c->d_M = nullptr; c->d_tile_table = nullptr; c->d_tile_off = nullptr; c->d_tile_I = nullptr;
-    c->d_runs = nullptr; c->d_tiles = nullptr;
+    c->d_runs = nullptr; c->d_tiles = nullptr; c->d_segs = nullptr; c->d_wave_seg = nullptr;
     c->eri_ready = false;
 }
 
@@ -346,8 +349,8 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     if (!c || !key) return fail("mi_set_option: null argument");
     std::string k(key);
     if (k == "runmax") c->opt_runmax = (int)value;           // takes effect at the next mi_eri_prepare
-    else if (k == "jk_variant") c->opt_jk_variant = (int)value;
-    else if (k == "jk_noatomic") c->opt_jk_noatomic = (int)value;
+    else if (k == "jk_waves") c->opt_jk_waves = (int)value; // takes effect at the next mi_eri_prepare
+    else if (k == "jk_nt") c->opt_jk_nt = (int)value;
     else return fail("mi_set_option: unknown key '%s'", key);
     return 0;
 }
@@ -955,7 +958,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     }
 
     // ---- 4. tiles and runs.  Run = tiles sharing (J,K,L), ordered by I; long runs are split.
-    const int RUNMAX = std::max(1, c->opt_runmax);
+    const int RUNMAX = 1 << 30; // runs are kept whole here (sharding unit); J/K work items are cut below
     std::vector<int> bpI(nbp), bpJ(nbp);
     for (int I = 0, n = 0; I < nblk; I++)
         for (int J = 0; J <= I; J++, n++) { bpI[n] = I; bpJ[n] = J; }
@@ -1008,6 +1011,70 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         for (size_t i = 0; i < tI.size(); i++) tI[i] = c->tiles[i].I;
         if (upload(&c->d_tile_I, tI)) return -1;
         if (upload(&c->d_runs, c->runs)) return -1;
+        // J/K work items ("segments"): runs cut into chunks; either one wave per item (longest first, the
+        // hardware dispatcher balances) or a fixed number of waves with equal-cost contiguous shares.
+        auto tile_cost = [&](int tid) {
+            int64_t nd = (tid + 1 < (int)c->tile_off.size() ? c->tile_off[tid + 1] : off) - c->tile_off[tid];
+            return (double)nd * 8.0 + 8192.0; // streamed bytes + fixed per-tile overhead
+        };
+        const int chunk = c->opt_runmax > 0 ? c->opt_runmax : (int)std::min<int64_t>(64, std::max<int64_t>(8, c->n_tiles / 2048));
+        std::vector<RunRec> segs;
+        std::vector<int> wave_seg;
+        int nw, w = 0;
+        if (c->opt_jk_waves <= 0) {
+            for (const RunRec &r : c->runs)
+                for (int t0 = 0; t0 < r.count; t0 += chunk) segs.push_back(RunRec{r.J, r.K, r.L, r.first + t0, std::min(chunk, r.count - t0)});
+            std::vector<double> cost(segs.size(), 0.0);
+            for (size_t q = 0; q < segs.size(); q++)
+                for (int t = 0; t < segs[q].count; t++) cost[q] += tile_cost(segs[q].first + t);
+            std::vector<int> ord(segs.size());
+            std::iota(ord.begin(), ord.end(), 0);
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+            std::vector<RunRec> sorted(segs.size());
+            for (size_t q = 0; q < segs.size(); q++) sorted[q] = segs[ord[q]];
+            segs.swap(sorted);
+            nw = (int)segs.size();
+            wave_seg.resize(nw + 1);
+            std::iota(wave_seg.begin(), wave_seg.end(), 0);
+            w = nw - 1;
+        } else {
+        nw = (int)std::min<int64_t>(c->opt_jk_waves, std::max<int64_t>(c->n_tiles, 1));
+        wave_seg.assign(nw + 1, 0);
+        double total_cost = 0.0;
+        for (int tid = 0; tid < (int)c->n_tiles; tid++) total_cost += tile_cost(tid);
+        double per = total_cost / nw, acc_cost = 0.0;
+        for (const RunRec &r : c->runs) {
+            RunRec cur{r.J, r.K, r.L, r.first, 0};
+            for (int t = 0; t < r.count; t++) {
+                int tid = r.first + t;
+                double tc = tile_cost(tid);
+                int wt = std::min(nw - 1, (int)((acc_cost + 0.5 * tc) / per));
+                acc_cost += tc;
+                if (wt != w) {
+                    if (cur.count) segs.push_back(cur);
+                    for (int x = w + 1; x <= wt; x++) wave_seg[x] = (int)segs.size();
+                    w = wt;
+                    cur = RunRec{r.J, r.K, r.L, tid, 0};
+                }
+                cur.count++;
+            }
+            if (cur.count) segs.push_back(cur);
+        }
+        }
+        for (int x = w + 1; x <= nw; x++) wave_seg[x] = (int)segs.size();
+        c->n_jk_waves = nw;
+        if (getenv("MI355_DEBUG")) {
+            int mx = 0, mn = 1 << 30, maxseg = 0;
+            for (int x = 0; x < nw; x++) {
+                int nt = 0;
+                for (int sgi = wave_seg[x]; sgi < wave_seg[x + 1]; sgi++) nt += segs[sgi].count;
+                mx = std::max(mx, nt); mn = std::min(mn, nt); maxseg = std::max(maxseg, wave_seg[x + 1] - wave_seg[x]);
+            }
+            fprintf(stderr, "[mi355] tiles=%ld runs=%zu segs=%zu waves=%d tiles/wave min=%d max=%d maxsegs/wave=%d\n",
+                    (long)c->n_tiles, c->runs.size(), segs.size(), nw, mn, mx, maxseg);
+        }
+        if (upload(&c->d_segs, segs)) return -1;
+        if (upload(&c->d_wave_seg, wave_seg)) return -1;
     }
     size_t freeb = 0, totb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totb));
@@ -1100,12 +1167,15 @@ extern "C" int mi_eri_get_stats(const mi_ctx *c, mi_eri_stats *out)
 // Partial blocks are added with FP64 global atomics into padded accumulators; the finalize kernel
 // forms J = 2 (Jacc + Jacc^T), K = Kacc + Kacc^T (tile values are pre-weighted, see put_tile).
 // =================================================================================================
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
 struct JkArgs {
     const double *tiles;
     const int64_t *tile_off;
     const int *tile_I;
-    const RunRec *runs;
-    int nruns;
+    const RunRec *runs;      // segments (runs cut at wave boundaries)
+    const int *wave_seg;     // [nwaves+1]
+    int nruns;               // number of waves
     const double *D; // padded [ldp][ldp]
     double *Jacc, *Kacc;
     int ld, nao;
@@ -1131,14 +1201,14 @@ __device__ inline double reduce8(const double v[8], int lane, int m2, int m1, in
     return red_select_xor(b[0], b[1], h0, m0);
 }
 
-template <bool WITH_J, bool WITH_K>
+template <bool WITH_J, bool WITH_K, bool NT>
 __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
 {
     const int lane = threadIdx.x;
-    const int run_id = blockIdx.x;
-    if (run_id >= A.nruns) return;
-    const RunRec R = A.runs[run_id];
     const int i = lane >> 3, k = lane & 7;
+    const int seg_end = A.wave_seg[blockIdx.x + 1];
+  for (int seg = A.wave_seg[blockIdx.x]; seg < seg_end; seg++) {
+    const RunRec R = A.runs[seg];
     const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
     const int ld = A.ld;
     const int bj = BLK, bk = min(BLK, A.nao - K0); // tiles are padded to 8 j-rows
@@ -1163,7 +1233,7 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
         const int I0 = A.tile_I[tid] * BLK;
         const int bi = min(BLK, A.nao - I0);
         const bool active = (i < bi) && (k < bk);
-        const double2 *__restrict__ T = reinterpret_cast<const double2 *>(A.tiles + A.tile_off[tid]) + (i * bk + k);
+        const d2_t *__restrict__ T = reinterpret_cast<const d2_t *>(A.tiles + A.tile_off[tid]) + (i * bk + k);
         const int cs = bi * bk; // double2 stride between (j,lp) chunks
         double dIJ[8], dIL[8];
 #pragma unroll
@@ -1180,7 +1250,8 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
                 double v[8];
 #pragma unroll
                 for (int lp = 0; lp < 4; lp++) {
-                    double2 x = active ? T[(size_t)(j * 4 + lp) * cs] : make_double2(0.0, 0.0);
+                    d2_t x = {0.0, 0.0};
+                    if (active) x = NT ? __builtin_nontemporal_load(&T[(size_t)(j * 4 + lp) * cs]) : T[(size_t)(j * 4 + lp) * cs];
                     v[2 * lp] = x.x; v[2 * lp + 1] = x.y;
                 }
                 const double *__restrict__ dJL = D + (size_t)(J0 + j) * ld + L0; // wave-uniform row
@@ -1231,142 +1302,9 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
         double r2 = reduce8(s, lane, 4, 2, 1); // lane holds l = k, summed over k-lanes
         atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + L0 + k], r2);
     }
+  } // segments of this wave
 }
 
-
-// Software-pipelined variant.  Tiles always hold 8 j-rows (zero padded); lanes outside a short (i,k)
-// block read a clamped in-range chunk: their products meet zero rows/columns of the padded density or
-// land in padded accumulator cells, so no masking is needed.  A ring of 4 row buffers keeps three rows
-// (12 KB per wave) plus the next tile's density rows in flight while the current row is digested.
-template <bool WITH_J, bool WITH_K, bool ATOMICS>
-__global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
-{
-    const int lane = threadIdx.x;
-    const int run_id = blockIdx.x;
-    if (run_id >= A.nruns) return;
-    const RunRec R = A.runs[run_id];
-    const int i = lane >> 3, k = lane & 7;
-    const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
-    const int ld = A.ld;
-    const int bk = min(BLK, A.nao - K0);
-    const int kc = min(k, bk - 1);
-    const double *__restrict__ D = A.D;
-
-    double dKL[8], dJK[8];
-#pragma unroll
-    for (int l = 0; l < 8; l++) dKL[l] = D[(size_t)(K0 + k) * ld + L0 + l];
-#pragma unroll
-    for (int j = 0; j < 8; j++) dJK[j] = D[(size_t)(J0 + j) * ld + K0 + k];
-    double kjl[8][8], jkl[8], kjk[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        jkl[j] = 0.0; kjk[j] = 0.0;
-#pragma unroll
-        for (int l = 0; l < 8; l++) kjl[j][l] = 0.0;
-    }
-
-    // ---- prologue: tile 0 descriptors, density rows and the first 4 tile rows
-    int I0 = A.tile_I[R.first] * BLK;
-    int bi = min(BLK, A.nao - I0);
-    const double2 *__restrict__ T = reinterpret_cast<const double2 *>(A.tiles + A.tile_off[R.first]) + (min(i, bi - 1) * bk + kc);
-    int cs = bi * bk;
-    double dIJ[8], dIL[8], dIK;
-#pragma unroll
-    for (int j = 0; j < 8; j++) dIJ[j] = D[(size_t)(I0 + i) * ld + J0 + j];
-#pragma unroll
-    for (int l = 0; l < 8; l++) dIL[l] = D[(size_t)(I0 + i) * ld + L0 + l];
-    dIK = D[(size_t)(I0 + i) * ld + K0 + k];
-    double2 ring[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int lp = 0; lp < 4; lp++) ring[r][lp] = T[(size_t)(r * 4 + lp) * cs];
-
-    for (int t = 0; t < R.count; t++) {
-        const bool has_next = (t + 1 < R.count);
-        const int tn = R.first + (has_next ? t + 1 : t);
-        // next tile: descriptors and density rows (issued early, consumed after this tile)
-        const int I0n = A.tile_I[tn] * BLK;
-        const int bin = min(BLK, A.nao - I0n);
-        const double2 *__restrict__ Tn = reinterpret_cast<const double2 *>(A.tiles + A.tile_off[tn]) + (min(i, bin - 1) * bk + kc);
-        const int csn = bin * bk;
-        double dIJn[8], dILn[8], dIKn;
-#pragma unroll
-        for (int j = 0; j < 8; j++) dIJn[j] = D[(size_t)(I0n + i) * ld + J0 + j];
-#pragma unroll
-        for (int l = 0; l < 8; l++) dILn[l] = D[(size_t)(I0n + i) * ld + L0 + l];
-        dIKn = D[(size_t)(I0n + i) * ld + K0 + k];
-
-        double kik = 0.0, jij[8], kil[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { jij[j] = 0.0; kil[j] = 0.0; }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            double v[8];
-#pragma unroll
-            for (int lp = 0; lp < 4; lp++) { v[2 * lp] = ring[j & 3][lp].x; v[2 * lp + 1] = ring[j & 3][lp].y; }
-            // refill this ring slot: row j+4 of this tile, or row j-4 of the next tile
-            if (j < 4) {
-#pragma unroll
-                for (int lp = 0; lp < 4; lp++) ring[j & 3][lp] = T[(size_t)((j + 4) * 4 + lp) * cs];
-            } else if (has_next) {
-#pragma unroll
-                for (int lp = 0; lp < 4; lp++) ring[j & 3][lp] = Tn[(size_t)((j - 4) * 4 + lp) * csn];
-            }
-            const double *__restrict__ dJL = D + (size_t)(J0 + j) * ld + L0; // wave-uniform row
-#pragma unroll
-            for (int l = 0; l < 8; l++) {
-                const double x = v[l];
-                if (WITH_K) {
-                    kik = fma(x, dJL[l], kik);
-                    kil[l] = fma(x, dJK[j], kil[l]);
-                    kjl[j][l] = fma(x, dIK, kjl[j][l]);
-                    kjk[j] = fma(x, dIL[l], kjk[j]);
-                }
-                if (WITH_J) {
-                    jij[j] = fma(x, dKL[l], jij[j]);
-                    jkl[l] = fma(x, dIJ[j], jkl[l]);
-                }
-            }
-        }
-        if (WITH_K) {
-            double r = reduce8(kil, lane, 4, 2, 1);
-            if (ATOMICS) {
-                atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik);
-                atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + L0 + k], r);
-            } else if (r + kik == 1.2345e300) A.Kacc[0] = r;
-        }
-        if (WITH_J) {
-            double r = reduce8(jij, lane, 4, 2, 1);
-            if (ATOMICS) atomicAdd(&A.Jacc[(size_t)(I0 + i) * ld + J0 + k], r);
-            else if (r == 1.2345e300) A.Jacc[0] = r;
-        }
-        I0 = I0n; T = Tn; cs = csn; dIK = dIKn;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { dIJ[j] = dIJn[j]; dIL[j] = dILn[j]; }
-    }
-    if (WITH_J) {
-        double r = reduce8(jkl, lane, 32, 16, 8);
-        if (ATOMICS) atomicAdd(&A.Jacc[(size_t)(K0 + k) * ld + L0 + i], r);
-        else if (r == 1.2345e300) A.Jacc[0] = r;
-    }
-    if (WITH_K) {
-        double r = reduce8(kjk, lane, 32, 16, 8);
-        double s[8];
-#pragma unroll
-        for (int l = 0; l < 8; l++) {
-            double col[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) col[j] = kjl[j][l];
-            s[l] = reduce8(col, lane, 32, 16, 8);
-        }
-        double r2 = reduce8(s, lane, 4, 2, 1);
-        if (ATOMICS) {
-            atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + K0 + k], r);
-            atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + L0 + k], r2);
-        } else if (r + r2 == 1.2345e300) A.Kacc[0] = r;
-    }
-}
 
 __global__ void pad_density_kernel(const double *D, double *Dp, int nao, int ld)
 {
@@ -1387,20 +1325,13 @@ __global__ void finalize_jk_kernel(const double *Jacc, const double *Kacc, doubl
 
 static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
 {
-    JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_runs, (int)c->runs.size(), c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao};
-    if (A.nruns == 0) return 0;
+    JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao};
+    if (c->n_tiles == 0) return 0;
     dim3 g(A.nruns), b(64);
-    if (c->opt_jk_variant == 1) {
-        if (c->opt_jk_noatomic) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, true, false>), g, b, 0, st, A);
-        else if (wj && wk) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, true, true>), g, b, 0, st, A);
-        else if (wj) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, false, true>), g, b, 0, st, A);
-        else hipLaunchKernelGGL((jk_tiles_pipe_kernel<false, true, true>), g, b, 0, st, A);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-    if (wj && wk) hipLaunchKernelGGL((jk_tiles_kernel<true, true>), g, b, 0, st, A);
-    else if (wj) hipLaunchKernelGGL((jk_tiles_kernel<true, false>), g, b, 0, st, A);
-    else hipLaunchKernelGGL((jk_tiles_kernel<false, true>), g, b, 0, st, A);
+    const bool nt = c->opt_jk_nt != 0;
+    if (wj && wk) { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<true, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<true, true, false>), g, b, 0, st, A); }
+    else if (wj) hipLaunchKernelGGL((jk_tiles_kernel<true, false, true>), g, b, 0, st, A);
+    else hipLaunchKernelGGL((jk_tiles_kernel<false, true, true>), g, b, 0, st, A);
     HIPCHK(hipGetLastError());
     return 0;
 }

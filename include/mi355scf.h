@@ -41,9 +41,10 @@ int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, int nbas, co
 void mi_ctx_destroy(mi_ctx *ctx);
 int mi_ctx_nao(const mi_ctx *ctx);
 
-/* Tunables (project-defined, no reference counterpart): "runmax" tiles per run (before
- * mi_eri_prepare), "jk_variant" 0 simple / 1 software-pipelined J/K kernel, "jk_noatomic" 1 = timing
- * experiment without the atomic adds (results invalid). */
+/* Tunables (project-defined, no reference counterpart), effective at the next mi_eri_prepare:
+ * "runmax" tiles per J/K work item (0 = auto), "jk_waves" 0 = one wave per work item, longest first;
+ * N > 0 = N waves with equal-cost contiguous shares;
+ * immediate: "jk_nt" 1 = nontemporal loads for the tile stream. */
 int mi_set_option(mi_ctx *ctx, const char *key, double value);
 
 /* One-electron integrals into device buffers (any of them may be NULL): overlap S, kinetic T, nuclear

@@ -14,21 +14,18 @@ n = mol.nao
 rng = np.random.default_rng(0)
 a = rng.normal(size=(n, n)); D = torch.as_tensor(a + a.T, device="cuda")
 ref = None
-for runmax in (8, 4, 16, 64):
+for runmax, waves in ((0, 0), (4, 0), (8, 0), (16, 0), (64, 0), (64, 4096)):
     eng = Engine(mol)
-    eng.set_option("runmax", runmax)
+    eng.set_option("runmax", runmax); eng.set_option("jk_waves", waves)
     st = eng.prepare_eri(1e-13)
     alg = 8.0 * st["n_unique_eri"] + 24.0 * n * n
-    for variant, noat in ((0, 0), (1, 0), (1, 1)):
-        eng.set_option("jk_variant", variant); eng.set_option("jk_noatomic", noat)
-        if not noat:
-            J, K = eng.get_jk(D)
-            if ref is None: ref = (J.clone(), K.clone())
-            err = max(float((J - ref[0]).abs().max()), float((K - ref[1]).abs().max()))
-        else:
-            err = float("nan")
+    for nt in (1,):
+        eng.set_option("jk_nt", nt)
+        J, K = eng.get_jk(D)
+        if ref is None: ref = (J.clone(), K.clone())
+        err = max(float((J - ref[0]).abs().max()), float((K - ref[1]).abs().max()))
         ms = min(eng.time_jk_kernel(D, reps=20) for _ in range(3))
-        print(json.dumps(dict(basis=basis, runmax=runmax, runs=st["n_runs"], variant=variant, noatomic=noat, ms=round(ms, 4),
+        print(json.dumps(dict(basis=basis, runmax=runmax, waves=waves, nt=nt, runs=st["n_runs"], ms=round(ms, 4),
                               alg_GBps=round(alg / ms / 1e6, 1), stored_GBps=round(st["stored_bytes"] / ms / 1e6, 1),
                               stored_MB=round(st["stored_bytes"] / 1e6, 1), maxdiff_vs_first=err)), flush=True)
     eng.close()
