@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--basis", default="cc-pVDZ")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eig", default="sp2", choices=["sp2", "eigh"], help="projector method inside the SCF step")
     args = ap.parse_args()
 
     import torch
@@ -74,6 +75,7 @@ def main():
 
     mol = Mole(atom=BENZENE, basis=args.basis, verbose=0).build()
     mf = RHF(mol)
+    mf.eig_method = args.eig
     if world > 1:
         mf.shard(rank, world)
     t0 = time.time()
@@ -115,7 +117,8 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"benzene RHF/{args.basis} SCF cycle (N_ao={n}, resident 8-fold ERI tiles)",
-                          "n_ao": n, "n_unique_eri": stats["n_unique_eri"], "parallelism": f"tile-run shard x{world}"},
+                          "n_ao": n, "n_unique_eri": stats["n_unique_eri"], "parallelism": f"tile-run shard x{world}",
+                          "density_from_fock": args.eig},
                "roofline": roof, "e_tot": st["e_tot"], "eri_seconds": stats["seconds_eri"], "setup_seconds": setup_s}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mol)

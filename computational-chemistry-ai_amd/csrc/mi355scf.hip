@@ -1798,3 +1798,85 @@ extern "C" int mi_xc_aow(mi_ctx *c, const double *d_ao, const double *d_wv, int6
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+// =================================================================================================
+// SP2 density-matrix purification helpers (row a11 without a diagonalisation): the X*X products are
+// rocBLAS DGEMMs; these kernels fuse everything else so one purification step is 2 launches.
+// =================================================================================================
+// bounds[0] = min_i (F_ii - R_i), bounds[1] = max_i (F_ii + R_i)   (Gershgorin), one block
+__global__ __launch_bounds__(256) void sp2_bounds_kernel(const double *F, int n, double *bounds)
+{
+    __shared__ double smin[256], smax[256];
+    double lo = 1e300, hi = -1e300;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        double d = F[(size_t)r * n + r], s = 0.0;
+        for (int c = 0; c < n; c++) s += fabs(F[(size_t)r * n + c]);
+        s -= fabs(d);
+        lo = fmin(lo, d - s); hi = fmax(hi, d + s);
+    }
+    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + o]);
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { bounds[0] = smin[0]; bounds[1] = smax[0]; }
+}
+
+__global__ __launch_bounds__(256) void sp2_init_kernel(const double *F, const double *bounds, int n, double *X)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * n) return;
+    int r = (int)(idx / n), c = (int)(idx - (size_t)r * n);
+    double emin = bounds[0], emax = bounds[1];
+    X[idx] = ((r == c ? emax : 0.0) - F[idx]) / (emax - emin);
+}
+
+// out <- X2 if |tr X2 - N| < |2 tr X - tr X2 - N| else 2X - X2 ; traces recomputed per block (2n loads)
+__global__ __launch_bounds__(256) void sp2_update_kernel(double *X, const double *X2, int n, double target, double *traces)
+{
+    __shared__ double s1[256], s2[256];
+    double a = 0.0, b = 0.0;
+    for (int r = threadIdx.x; r < n; r += 256) { a += X[(size_t)r * n + r]; b += X2[(size_t)r * n + r]; }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    const double tx = s1[0], tx2 = s2[0];
+    const bool sq = fabs(tx2 - target) < fabs(2.0 * tx - tx2 - target);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { traces[0] = tx; traces[1] = tx2; }
+    // the update goes to a separate buffer (after the two trace slots), so no block races with another
+    // block's diagonal reads of X
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)n * n) {
+        double x = X[idx], x2 = X2[idx];
+        traces[2 + idx] = sq ? x2 : 2.0 * x - x2; // out buffer follows the 2 trace slots
+    }
+}
+
+extern "C" int mi_sp2_init(mi_ctx *c, const double *d_F, double *d_X, double *d_work, void *stream)
+{
+    if (!c || !d_F || !d_X || !d_work) return fail("mi_sp2_init: null argument");
+    int n = c->nao;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sp2_bounds_kernel, dim3(1), dim3(256), 0, st, d_F, n, d_work);
+    hipLaunchKernelGGL(sp2_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, d_F, d_work, n, d_X);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// d_out_with_traces: [2 + n*n] doubles: traces (tr X, tr X2 of the INPUT) then the updated matrix
+extern "C" int mi_sp2_update(mi_ctx *c, double *d_X, const double *d_X2, double n_occ, double *d_out_with_traces, void *stream)
+{
+    if (!c || !d_X || !d_X2 || !d_out_with_traces) return fail("mi_sp2_update: null argument");
+    int n = c->nao;
+    hipLaunchKernelGGL(sp2_update_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_X, d_X2, n, n_occ,
+                       d_out_with_traces);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

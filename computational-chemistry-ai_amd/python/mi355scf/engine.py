@@ -65,6 +65,8 @@ def lib():
         L.mi_xc_rho.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
         L.mi_xc_eval.argtypes = [ip, dp, ctypes.c_int, vp, vp, i64, ctypes.c_int, vp, vp, vp, vp, vp]
         L.mi_xc_aow.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
+        L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
+        L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_c2s_table.argtypes = [ctypes.c_int, dp]
         L.mi_rys_roots_host.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp]
         _lib = L
@@ -223,6 +225,13 @@ class Engine:
         aow = self._new(self.nao, ng)
         _check(lib().mi_xc_aow(self._h, ao.data_ptr(), wv.data_ptr(), ng, int(gga), aow.data_ptr(), self._stream()))
         return aow
+
+    # --- row a11: SP2 purification helpers ------------------------------------------------------
+    def sp2_init(self, f_orth, X, work):
+        _check(lib().mi_sp2_init(self._h, f_orth.data_ptr(), X.data_ptr(), work.data_ptr(), self._stream()))
+
+    def sp2_update(self, X, X2, nocc, out):
+        _check(lib().mi_sp2_update(self._h, X.data_ptr(), X2.data_ptr(), float(nocc), out.data_ptr(), self._stream()))
 
     # --- row a10 -------------------------------------------------------------------------------
     def diis_errvec(self, sdf, out):

@@ -82,6 +82,13 @@ class SCF:
     direct_scf_tol = 1e-13
     conv_check = True
     xc = None  # HF
+    # How the occupied-space projector is obtained from the Fock matrix inside the SCF loop:
+    #  'sp2'  trace-correcting second-order spectral projection (Niklasson, PRB 66, 155115 (2002)) --
+    #         GEMM-only (rocBLAS FP64 MFMA), no host sync; the converged density is the same aufbau
+    #         projector the diagonalisation gives.  mo_energy/mo_coeff come from one `eigh` after convergence.
+    #  'eigh' hipSOLVER generalised eigenproblem every cycle (what PySCF's `eig` does [MEM]).
+    eig_method = "sp2"
+    sp2_tol = 1e-11
 
     def __init__(self, mol):
         if not isinstance(mol, Mole):
@@ -188,6 +195,43 @@ class SCF:
         e, c = torch.linalg.eigh(Li @ f @ Li.T)
         return e, Li.T @ c
 
+    def _density_sp2(self, f, nocc):
+        """D = 2 P_occ(F) without diagonalisation.  Returns None if the purification does not converge
+        (e.g. vanishing HOMO-LUMO gap); the caller then falls back to `eigh`."""
+        Li = self._Linv
+        fo = Li @ f @ Li.T
+        n = fo.shape[0]
+        if nocc == 0 or nocc >= n:
+            return None
+        eng = self.engine
+        buf = getattr(self, "_sp2_buf", None)
+        if buf is None or buf[0].numel() != 2 + n * n:
+            buf = [torch.empty(2 + n * n, dtype=torch.float64, device=fo.device) for _ in range(2)]
+            self._sp2_buf = buf
+            self._sp2_x2 = torch.empty(n, n, dtype=torch.float64, device=fo.device)
+        cur = 0
+        X = buf[cur][2:].view(n, n)
+        eng.sp2_init(fo.contiguous(), X, buf[1 - cur])
+        X2 = self._sp2_x2
+        nit = getattr(self, "_sp2_iters", 24)
+        target = float(nocc)
+        done = 0
+        for attempt in range(6):
+            for _ in range(nit - done):
+                torch.matmul(X, X, out=X2)
+                eng.sp2_update(X, X2, target, buf[1 - cur])   # one fused launch: traces, branch, update
+                cur = 1 - cur
+                X = buf[cur][2:].view(n, n)
+            done = nit
+            torch.matmul(X, X, out=X2)
+            tr = torch.stack([torch.trace(X), torch.trace(X2)]).cpu()
+            err = float(tr[0] - tr[1])          # = sum lambda (1 - lambda) >= 0
+            if abs(err) < self.sp2_tol and abs(float(tr[0]) - target) < 1e-8:
+                self._sp2_iters = max(8, nit - 2) if attempt == 0 else nit + 2
+                return 2.0 * (Li.T @ X @ Li)
+            nit += 8
+        return None
+
     def make_rdm1(self, mo_coeff=None, mo_occ=None):
         if mo_coeff is None:
             if self._dm is not None:
@@ -247,22 +291,32 @@ class SCF:
         st["diis"] = DeviceDIIS(eng, self.diis_space)
         return st
 
-    def _step(self, st, use_diis=True):
+    def _step(self, st, use_diis=True, want_mo=False):
         """One SCF cycle: Fock (+CDIIS) -> eig -> density -> J/K -> energy, orbital gradient.  This is
         the unit bench.py times ("SCF iteration")."""
         S, h1, nocc = self._S, self._h1, st["nocc"]
         f = h1 + st["vhf"]
         if use_diis and st["cycle"] >= self.diis_start_cycle:
             f = st["diis"].update(S, st["dm"], f)
-        mo_e, mo_c = self._eig(f)
-        co = mo_c[:, :nocc]
-        dm = 2.0 * co @ co.T
+        dm = self._density_sp2(f, nocc) if (self.eig_method == "sp2" and not want_mo) else None
+        if dm is None:
+            mo_e, mo_c = self._eig(f)
+            co = mo_c[:, :nocc]
+            dm = 2.0 * co @ co.T
+            st.update(mo_e=mo_e, mo_c=mo_c)
+        else:
+            st.pop("mo_e", None)
         vhf, e2 = self._veff(dm)
         e_last = st["e_tot"]
-        e_tot = float(torch.sum(dm * h1) + e2) + st["enuc"]
-        g = 2.0 * mo_c[:, nocc:].T @ (h1 + vhf) @ co
-        gnorm = float(torch.linalg.norm(g)) / max(np.sqrt(g.numel()), 1.0)
-        st.update(dm=dm, vhf=vhf, e_tot=e_tot, mo_e=mo_e, mo_c=mo_c, de=e_tot - e_last, gnorm=gnorm)
+        fock = h1 + vhf
+        fds = fock @ dm @ S
+        comm = self._Linv @ (fds - fds.T) @ self._Linv.T   # [F', D'] in the orthonormal basis
+        nvo = max((S.shape[0] - nocc) * nocc, 1)
+        # |g| = |2 F_vo| = |[F',D']|_F / sqrt(2)  (identical to PySCF's get_grad norm [MEM])
+        vals = torch.stack([torch.sum(dm * h1) + e2, torch.linalg.norm(comm)]).cpu()   # one host sync
+        e_tot = float(vals[0]) + st["enuc"]
+        gnorm = float(vals[1]) / np.sqrt(2.0) / np.sqrt(nvo)
+        st.update(dm=dm, vhf=vhf, e_tot=e_tot, de=e_tot - e_last, gnorm=gnorm)
         st["cycle"] += 1
         return st
 
@@ -284,9 +338,9 @@ class SCF:
         self.cycles = st["cycle"]
         self.timing["loop_seconds"] = time.time() - t_loop
         if self.converged and self.conv_check:
-            self._step(st, use_diis=False)
+            self._step(st, use_diis=False, want_mo=True)
             self._log(4, f"Extra cycle  E= {st['e_tot']:.15g}  delta_E= {st['de']:.3g}")
-        if "mo_e" not in st:  # max_cycle == 0
+        if "mo_e" not in st:  # not converged (or max_cycle == 0): orbitals of the last Fock matrix
             st["mo_e"], st["mo_c"] = self._eig(self._h1 + st["vhf"])
         self._dm, self._vhf = st["dm"], st["vhf"]
         self.e_tot = float(st["e_tot"])

@@ -97,6 +97,16 @@ int mi_diis_dots(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int n, 
                  void *stream);
 
 
+/* ---- density from the Fock matrix without diagonalisation (row a11) ----------------------------- */
+/* SP2 purification (Niklasson 2002) in an orthonormal basis; the X*X products are the caller's DGEMMs.
+ * mi_sp2_init: X0 = (emax*I - F)/(emax - emin) with Gershgorin bounds; d_work: >= 2 doubles.
+ * mi_sp2_update: given X and X2 = X*X writes {tr X, tr X2, X_next[n*n]} to d_out_with_traces, where
+ * X_next = X2 if |tr X2 - n_occ| < |2 tr X - tr X2 - n_occ| else 2X - X2.
+ * Stand in for the LAPACK eig inside PySCF's SCF.eig (templates/calculate_energy.py:155 -> kernel()). */
+int mi_sp2_init(mi_ctx *ctx, const double *d_F, double *d_X, double *d_work, void *stream);
+int mi_sp2_update(mi_ctx *ctx, double *d_X, const double *d_X2, double n_occ, double *d_out_with_traces,
+                  void *stream);
+
 /* ---- DFT -------------------------------------------------------------- */
 
 /* Becke fuzzy-cell weights for `ng` atom-centred grid points: d_coords[ng][3] (Bohr), d_atom_of[ng]
