@@ -1,0 +1,49 @@
+"""The two in-scope reference templates import and build molecules UNCHANGED against the drop-in packages
+(`pyscf`, `gpu4pyscf`, `cupy`, `rdkit` stand-ins).  Runs here (CPU container, reference mounted); skipped on
+the GPU box where /root/reference does not exist.  The SCF itself needs a GPU (tests/test_gpu_template_flow.py)."""
+import importlib.util
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+TEMPLATES = "/root/reference/templates"
+pytestmark = pytest.mark.skipif(not os.path.isdir(TEMPLATES), reason="reference not mounted")
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(TEMPLATES, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_calculate_energy_template_imports_and_builds_mol(capsys):
+    mod = _load("calculate_energy")
+    assert mod.GPU4PYSCF_AVAILABLE is True          # cupy + gpu4pyscf imports succeeded
+    atoms, coords = mod.smiles_to_xyz("C=O")
+    assert atoms == ["C", "O", "H", "H"] and coords.shape == (4, 3)
+    buf = io.StringIO()
+    mol = mod.create_pyscf_mol(atoms, coords, "6-31G(d)", 0, 0, output_stream=buf)
+    assert (mol.natm, mol.nelectron, mol.nao) == (4, 16, 32)     # BASELINE config 1
+    atoms, coords = mod.smiles_to_xyz("c1ccccc1")
+    mol = mod.create_pyscf_mol(atoms, coords, "cc-pVDZ")
+    assert (mol.natm, mol.nelectron, mol.nao) == (12, 42, 114)   # BASELINE config 2
+    # analyze_orbitals works on NumPy results
+    class _MF:
+        mo_energy = np.array([-1.0, -0.5, 0.2])
+        mo_occ = np.array([2.0, 2.0, 0.0])
+    info = mod.analyze_orbitals(_MF(), mol)
+    assert info["homo_idx"] == 1 and abs(info["gap"] - 0.7) < 1e-12
+
+
+def test_optimize_geometry_template_imports_and_builds_mol():
+    mod = _load("optimize_geometry")
+    atoms, coords = mod.smiles_to_xyz("CC(C)Cc1ccc(cc1)C(C)C(=O)O")
+    assert len(atoms) == 33
+    mol = mod.create_pyscf_mol(atoms, coords, "def2-TZVP")
+    assert (mol.nelectron, mol.nao) == (112, 573)                # BASELINE config 5
+    assert mol.atom_coords().shape == (33, 3)
+    assert callable(mod.optimize)
