@@ -1880,3 +1880,163 @@ extern "C" int mi_sp2_update(mi_ctx *c, double *d_X, const double *d_X2, double 
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+// =================================================================================================
+// Analytic nuclear gradient, one-electron part (row a15):
+//   g[X] += 2 sum_{mu on X, nu} [ D_mu,nu <d mu|T+V|nu> - W_mu,nu <d mu|nu> ]  (basis-function derivative)
+//   g[C] -= 2 sum_{mu,nu} D_mu,nu <d mu|v_C|nu>                               (Hellmann-Feynman, via
+//                                                                               translational invariance)
+// One thread per ORDERED shell pair (ish, jsh); the derivative acts on the first shell.  d/dA_x of a
+// primitive cartesian Gaussian = 2a (a+1_x) - a_x (a-1_x), applied inside the primitive loop.
+// =================================================================================================
+struct Grad1eArgs {
+    const int32_t *atm, *bas;
+    const double *env;
+    const int *shell_ao;
+    const double *c2s;
+    int c2s_off[LMAX + 2];
+    RysDev rys;
+    int natm, nbas, nao;
+    const double *D, *W; // [nao][nao]
+    double *grad;        // [natm][3]
+};
+
+__global__ __launch_bounds__(64) void int1e_grad_kernel(Grad1eArgs A)
+{
+    int pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= A.nbas * A.nbas) return;
+    int ish = pid / A.nbas, jsh = pid - ish * A.nbas;
+    const int32_t *bi = A.bas + ish * BAS_SLOTS, *bj = A.bas + jsh * BAS_SLOTS;
+    int la = bi[1], lb = bj[1];
+    const double *ra = A.env + A.atm[bi[0] * ATM_SLOTS + 1], *rb = A.env + A.atm[bj[0] * ATM_SLOTS + 1];
+    int nca = (la + 1) * (la + 2) / 2, ncb = (lb + 1) * (lb + 2) / 2;
+    int nsa = 2 * la + 1, nsb = 2 * lb + 1;
+    int ao_i = A.shell_ao[ish], ao_j = A.shell_ao[jsh];
+    const double *ca = A.c2s + A.c2s_off[la], *cb = A.c2s + A.c2s_off[lb];
+    // back-transform the density blocks to cartesian components
+    double Dc[NC1 * NC1], Wc[NC1 * NC1];
+    for (int a = 0; a < nca; a++)
+        for (int b = 0; b < ncb; b++) {
+            double sd = 0.0, sw = 0.0;
+            for (int i = 0; i < nsa; i++) {
+                double t = 0.0, u = 0.0;
+                for (int j = 0; j < nsb; j++) {
+                    t += A.D[(size_t)(ao_i + i) * A.nao + ao_j + j] * cb[b * nsb + j];
+                    u += A.W[(size_t)(ao_i + i) * A.nao + ao_j + j] * cb[b * nsb + j];
+                }
+                sd += ca[a * nsa + i] * t; sw += ca[a * nsa + i] * u;
+            }
+            Dc[a * ncb + b] = sd; Wc[a * ncb + b] = sw;
+        }
+    double gA[3] = {0.0, 0.0, 0.0};
+    double AB[3] = {ra[0] - rb[0], ra[1] - rb[1], ra[2] - rb[2]};
+    for (int ip = 0; ip < bi[2]; ip++)
+        for (int jp = 0; jp < bj[2]; jp++) {
+            double a = A.env[bi[5] + ip], b = A.env[bj[5] + jp];
+            double cc = A.env[bi[6] + ip] * A.env[bj[6] + jp];
+            double p = a + b, mu = a * b / p, h = 0.5 / p;
+            double ex = exp(-mu * (AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2]));
+            double P[3], PA[3], PB[3];
+            for (int d = 0; d < 3; d++) { P[d] = (a * ra[d] + b * rb[d]) / p; PA[d] = P[d] - ra[d]; PB[d] = P[d] - rb[d]; }
+            double s[3][LMAX + 3][LMAX + 3]; // s[d][i][j], i <= la+1, j <= lb+2
+            for (int d = 0; d < 3; d++) {
+                s[d][0][0] = 1.0;
+                for (int i = 0; i <= la; i++) s[d][i + 1][0] = PA[d] * s[d][i][0] + (i > 0 ? i * h * s[d][i - 1][0] : 0.0);
+                for (int j = 0; j <= lb + 1; j++)
+                    for (int i = 0; i <= la + 1; i++)
+                        s[d][i][j + 1] = PB[d] * s[d][i][j] + (i > 0 ? i * h * s[d][i - 1][j] : 0.0) + (j > 0 ? j * h * s[d][i][j - 1] : 0.0);
+            }
+            double pref = cc * ex * pow(M_PI / p, 1.5);
+            // overlap and kinetic: 1-D factors S(i,j), T(i,j) for i in {a-1, a, a+1}
+            for (int ia = 0; ia < nca; ia++) {
+                int pa[3];
+                cart_pow(la, ia, pa[0], pa[1], pa[2]);
+                for (int ib = 0; ib < ncb; ib++) {
+                    int pb[3];
+                    cart_pow(lb, ib, pb[0], pb[1], pb[2]);
+                    double s0[3], t0[3], sd[3], td[3]; // plain and differentiated 1-D factors
+                    for (int d = 0; d < 3; d++) {
+                        int i = pa[d], j = pb[d];
+                        auto S1 = [&](int ii) { return s[d][ii][j]; };
+                        auto T1 = [&](int ii) {
+                            double t = -2.0 * b * (2 * j + 1) * s[d][ii][j] + 4.0 * b * b * s[d][ii][j + 2];
+                            if (j >= 2) t += j * (j - 1) * s[d][ii][j - 2];
+                            return -0.5 * t;
+                        };
+                        s0[d] = S1(i); t0[d] = T1(i);
+                        sd[d] = 2.0 * a * S1(i + 1) - (i > 0 ? i * S1(i - 1) : 0.0);
+                        td[d] = 2.0 * a * T1(i + 1) - (i > 0 ? i * T1(i - 1) : 0.0);
+                    }
+                    double dc = Dc[ia * ncb + ib], wc = Wc[ia * ncb + ib];
+                    for (int x = 0; x < 3; x++) {
+                        int y = (x + 1) % 3, z = (x + 2) % 3;
+                        double dS = sd[x] * s0[y] * s0[z];
+                        double dT = td[x] * s0[y] * s0[z] + sd[x] * t0[y] * s0[z] + sd[x] * s0[y] * t0[z];
+                        gA[x] += 2.0 * pref * (dc * dT - wc * dS);
+                    }
+                }
+            }
+            // nuclear attraction with the differentiated bra: Rys, nroots = (la+lb+1)/2 + 1
+            int nr = (la + lb + 1) / 2 + 1;
+            double pv = cc * ex * 2.0 * M_PI / p;
+            for (int ic = 0; ic < A.natm; ic++) {
+                double Z = A.atm[ic * ATM_SLOTS + 0];
+                if (Z == 0.0) continue;
+                const double *C = A.env + A.atm[ic * ATM_SLOTS + 1];
+                double PC[3] = {P[0] - C[0], P[1] - C[1], P[2] - C[2]};
+                double xarg = p * (PC[0] * PC[0] + PC[1] * PC[1] + PC[2] * PC[2]);
+                double gc[3] = {0.0, 0.0, 0.0};
+                for (int r = 0; r < nr; r++) {
+                    double u = rys_eval(A.rys, nr, r, xarg), w = rys_eval(A.rys, nr, nr + r, xarg);
+                    double g[3][2 * LMAX + 2][LMAX + 1];
+                    double b10 = (1.0 - u) * h;
+                    for (int d = 0; d < 3; d++) {
+                        double c00 = PA[d] - u * PC[d];
+                        g[d][0][0] = 1.0;
+                        for (int i = 0; i < la + lb + 1; i++) g[d][i + 1][0] = c00 * g[d][i][0] + (i > 0 ? i * b10 * g[d][i - 1][0] : 0.0);
+                        for (int j = 0; j < lb; j++)
+                            for (int i = 0; i <= la + lb - j; i++) g[d][i][j + 1] = g[d][i + 1][j] + AB[d] * g[d][i][j];
+                    }
+                    double f = -Z * pv * w;
+                    for (int ia = 0; ia < nca; ia++) {
+                        int pa[3];
+                        cart_pow(la, ia, pa[0], pa[1], pa[2]);
+                        for (int ib = 0; ib < ncb; ib++) {
+                            int pb[3];
+                            cart_pow(lb, ib, pb[0], pb[1], pb[2]);
+                            double v0[3], vd[3];
+                            for (int d = 0; d < 3; d++) {
+                                int i = pa[d], j = pb[d];
+                                v0[d] = g[d][i][j];
+                                vd[d] = 2.0 * a * g[d][i + 1][j] - (i > 0 ? i * g[d][i - 1][j] : 0.0);
+                            }
+                            double dc = f * Dc[ia * ncb + ib];
+                            gc[0] += dc * vd[0] * v0[1] * v0[2];
+                            gc[1] += dc * v0[0] * vd[1] * v0[2];
+                            gc[2] += dc * v0[0] * v0[1] * vd[2];
+                        }
+                    }
+                }
+                for (int x = 0; x < 3; x++) {
+                    gA[x] += 2.0 * gc[x];
+                    atomicAdd(&A.grad[ic * 3 + x], -2.0 * gc[x]);
+                }
+            }
+        }
+    for (int x = 0; x < 3; x++) atomicAdd(&A.grad[bi[0] * 3 + x], gA[x]);
+}
+
+extern "C" int mi_grad_1e(mi_ctx *c, const double *d_D, const double *d_W, double *d_grad, void *stream)
+{
+    if (!c || !d_D || !d_W || !d_grad) return fail("mi_grad_1e: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    Grad1eArgs A;
+    A.atm = c->d_atm; A.bas = c->d_bas; A.env = c->d_env; A.shell_ao = c->d_shell_ao; A.c2s = c->d_c2s;
+    for (int i = 0; i <= LMAX + 1; i++) A.c2s_off[i] = c->c2s_off[i];
+    A.rys = c->rys; A.natm = c->natm; A.nbas = c->nbas; A.nao = c->nao;
+    A.D = d_D; A.W = d_W; A.grad = d_grad;
+    int n = c->nbas * c->nbas;
+    hipLaunchKernelGGL(int1e_grad_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, A);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -67,6 +67,7 @@ def lib():
         L.mi_xc_aow.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
+        L.mi_grad_1e.argtypes = [vp, vp, vp, vp, vp]
         L.mi_c2s_table.argtypes = [ctypes.c_int, dp]
         L.mi_rys_roots_host.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp]
         _lib = L
@@ -225,6 +226,10 @@ class Engine:
         aow = self._new(self.nao, ng)
         _check(lib().mi_xc_aow(self._h, ao.data_ptr(), wv.data_ptr(), ng, int(gga), aow.data_ptr(), self._stream()))
         return aow
+
+    # --- row a15: gradient pieces -----------------------------------------------------------------
+    def grad_1e(self, D, W, grad):
+        _check(lib().mi_grad_1e(self._h, D.data_ptr(), W.data_ptr(), grad.data_ptr(), self._stream()))
 
     # --- row a11: SP2 purification helpers ------------------------------------------------------
     def sp2_init(self, f_orth, X, work):

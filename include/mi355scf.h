@@ -136,6 +136,12 @@ int mi_xc_eval(const int32_t *kinds, const double *coefs, int nterms, const doub
 int mi_xc_aow(mi_ctx *ctx, const double *d_ao, const double *d_wv, int64_t ng, int gga, double *d_aow,
               void *stream);
 
+/* ---- analytic nuclear gradient ---------------------------------------------- */
+/* d_grad[natm][3] += 2 sum D <d mu|T+V|nu> - 2 sum W <d mu|nu> + Hellmann-Feynman terms.  d_W is the
+ * energy-weighted density (D F D / 2).  Replaces libcint int1e_ipovlp/ipkin/ipnuc/iprinv [MEM], reached
+ * through optimize(mf) -> mf.nuc_grad_method() (templates/optimize_geometry.py:99). */
+int mi_grad_1e(mi_ctx *ctx, const double *d_D, const double *d_W, double *d_grad, void *stream);
+
 /* Real-solid-harmonic coefficient table used by the kernels: out[ncart(l)][2l+1] (host). */
 int mi_c2s_table(int l, double *out);
 
