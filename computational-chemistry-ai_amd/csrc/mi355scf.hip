@@ -177,6 +177,9 @@ struct PairRec { // one shell pair (l_i >= l_j)
 };
 
 struct PairClass {
+    // gradient variants of each (sorted) pair: [orientation 0: first = sh_i | 1: first = sh_j][0: l+1 | 1: l-1]
+    std::vector<PairRec> g_recs[2][2];
+    PairRec *d_g_recs[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int la, lb;
     int ne;                        // number of [e0| cartesian components, e = la..la+lb
     int nsab;                      // (2la+1)(2lb+1)
@@ -207,6 +210,9 @@ struct mi_ctx {
     PairClass pc[NPC];
     double *d_prim = nullptr;            // all primitive-pair records
     double *d_M = nullptr;               // all transformation matrices
+    std::vector<double> h_prim, h_M;     // host copies (gradient variants are appended lazily)
+    double tol = 1e-13;
+    bool grad_ready = false;
     // component index tables per class quadruple (built lazily)
     // tiles
     int64_t n_tiles = 0;
@@ -322,6 +328,12 @@ static void free_eri(mi_ctx *c)
         if (c->pc[i].d_recs) hipFree(c->pc[i].d_recs);
         if (c->pc[i].d_q) hipFree(c->pc[i].d_q);
         c->pc[i].d_recs = nullptr; c->pc[i].d_q = nullptr;
+        for (int o = 0; o < 2; o++)
+            for (int sg = 0; sg < 2; sg++) {
+                if (c->pc[i].d_g_recs[o][sg]) hipFree(c->pc[i].d_g_recs[o][sg]);
+                c->pc[i].d_g_recs[o][sg] = nullptr;
+                c->pc[i].g_recs[o][sg].clear();
+            }
         c->pc[i].recs.clear(); c->pc[i].q.clear();
     }
     void *ptrs[] = {c->d_prim, c->d_M, c->d_tile_table, c->d_tile_off, c->d_tile_I, c->d_runs, c->d_tiles, c->d_segs, c->d_wave_seg};
@@ -537,6 +549,7 @@ struct EriArgs {
     double *work;            // [ntask][ncomp]
     RysDev rys;
     int diag;                // 1: Schwarz mode, ket == bra and task b -> (b,b)
+    int swap;                // 1: the task's (bra index, ket index) address (ket[], bra[]) instead
 };
 
 __device__ inline void find_task(const int64_t *prefix, int nbra, int64_t t, int &ib, int &ik)
@@ -559,6 +572,7 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
     int ib, ik;
     if (A.diag) { ib = (int)task; ik = ib; }
     else find_task(A.prefix, A.nbra, task, ib, ik);
+    if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
     const int n = A.nroots, tsz = A.tsz, M1 = A.mmax + 1;
     const int ncd = cd.nprim, nPQ = ab.nprim * ncd;
@@ -850,7 +864,9 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     for (int l = 0; l <= LMAX; l++) c2s_generic(l, c2s[l]);
 
     // ---- 1. shell pairs, primitive-pair records, transformation matrices
-    std::vector<double> prim, Mbuf;
+    std::vector<double> &prim = c->h_prim, &Mbuf = c->h_M;
+    prim.clear(); Mbuf.clear();
+    c->tol = tol; c->grad_ready = false;
     for (int la = 0; la <= LMAX; la++)
         for (int lb = 0; lb <= la; lb++) {
             PairClass &P = c->pc[pc_index(la, lb)];
@@ -2038,5 +2054,294 @@ extern "C" int mi_grad_1e(mi_ctx *c, const double *d_D, const double *d_W, doubl
     int n = c->nbas * c->nbas;
     hipLaunchKernelGGL(int1e_grad_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, A);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// =================================================================================================
+// Analytic nuclear gradient, two-electron part (row a15).
+//
+//   dE2/dR_X = 2 sum_{mu on X; nu,lam,sig} (d mu nu|lam sig) G,  G = D_mn D_ls - (hyb/4)(D_ml D_ns + D_ms D_nl)
+//
+// For every Schwarz-surviving canonical shell quartet the four role permutations (ij|kl),(ji|kl),(kl|ij),
+// (lk|ij) are evaluated with the derivative on the FIRST shell.  d/dA of a contracted shell of angular
+// momentum l is a combination of an (l+1) shell with coefficients 2*alpha*c and an (l-1) shell with
+// coefficients c, so the same Rys kernel produces the two [e0|f0] blocks; `eri_grad_contract` applies
+// HRR + derivative + cart->sph folded into per-pair matrices, contracts with G and adds 4*w_q*sum to
+// grad[atom of the first shell].
+// =================================================================================================
+static void build_M_deriv(int l1, int l2, int sign, const double AB[3], const std::vector<double> &c1,
+                          const std::vector<double> &c2, double *M /* [3][ns1*ns2][ne'] */)
+{
+    int lp = l1 + sign;
+    int ns1 = 2 * l1 + 1, ns2 = 2 * l2 + 1, ne = ne_of(lp, l2);
+    std::fill(M, M + (size_t)3 * ns1 * ns2 * ne, 0.0);
+    int eoff[2 * LMAX + 4];
+    eoff[lp] = 0;
+    for (int e = lp; e < lp + l2 + 1; e++) eoff[e + 1] = eoff[e] + ncart(e);
+    double pw[3][LMAX + 1];
+    for (int d = 0; d < 3; d++) { pw[d][0] = 1.0; for (int k = 1; k <= LMAX; k++) pw[d][k] = pw[d][k - 1] * AB[d]; }
+    int ia = 0;
+    for (int ax = l1; ax >= 0; ax--)
+        for (int ay = l1 - ax; ay >= 0; ay--, ia++) {
+            int a[3] = {ax, ay, l1 - ax - ay};
+            for (int x = 0; x < 3; x++) {
+                double dcoef;
+                int ap[3] = {a[0], a[1], a[2]};
+                if (sign > 0) { ap[x] += 1; dcoef = 1.0; }
+                else { if (a[x] == 0) continue; ap[x] -= 1; dcoef = -(double)a[x]; }
+                int ib = 0;
+                for (int bx = l2; bx >= 0; bx--)
+                    for (int by = l2 - bx; by >= 0; by--, ib++) {
+                        int bz = l2 - bx - by;
+                        for (int ix = 0; ix <= bx; ix++)
+                            for (int iy = 0; iy <= by; iy++)
+                                for (int iz = 0; iz <= bz; iz++) {
+                                    double coef = dcoef * binom(bx, ix) * binom(by, iy) * binom(bz, iz) * pw[0][bx - ix] * pw[1][by - iy] * pw[2][bz - iz];
+                                    int deg = lp + ix + iy + iz;
+                                    int e = eoff[deg] + cart_index(deg, ap[0] + ix, ap[1] + iy);
+                                    for (int sa = 0; sa < ns1; sa++) {
+                                        double v1 = c1[(size_t)ia * ns1 + sa];
+                                        if (v1 == 0.0) continue;
+                                        for (int sb = 0; sb < ns2; sb++) {
+                                            double v2 = c2[(size_t)ib * ns2 + sb];
+                                            if (v2 != 0.0) M[((size_t)x * ns1 * ns2 + sa * ns2 + sb) * ne + e] += v1 * v2 * coef;
+                                        }
+                                    }
+                                }
+                    }
+            }
+        }
+}
+
+static int prepare_grad_records(mi_ctx *c)
+{
+    if (c->grad_ready) return 0;
+    std::vector<std::vector<double>> c2s(LMAX + 1);
+    for (int l = 0; l <= LMAX; l++) c2s_generic(l, c2s[l]);
+    std::vector<double> &prim = c->h_prim, &Mbuf = c->h_M;
+    for (int ci = 0; ci < NPC; ci++) {
+        PairClass &P = c->pc[ci];
+        for (int o = 0; o < 2; o++)
+            for (int sg = 0; sg < 2; sg++) P.g_recs[o][sg].assign(P.recs.size(), PairRec{-1, -1, 0, 0, 0, 0, 0, 0});
+        for (size_t r = 0; r < P.recs.size(); r++) {
+            for (int o = 0; o < 2; o++) {
+                int s1 = o == 0 ? P.recs[r].sh_i : P.recs[r].sh_j, s2 = o == 0 ? P.recs[r].sh_j : P.recs[r].sh_i;
+                const ShellH &I = c->shells[s1], &J = c->shells[s2];
+                double AB[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+                double r2 = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
+                for (int sg = 0; sg < 2; sg++) {
+                    int sign = sg == 0 ? +1 : -1;
+                    if (I.l + sign < 0) continue;
+                    PairRec R;
+                    R.sh_i = s1; R.sh_j = s2; R.ao_i = I.ao; R.ao_j = J.ao; R.pad = 0;
+                    R.prim_off = (int)(prim.size() / 8);
+                    int np = 0;
+                    for (int ip = 0; ip < I.nprim; ip++)
+                        for (int jp = 0; jp < J.nprim; jp++) {
+                            double a = I.exps[ip], b = J.exps[jp], p = a + b, mu = a * b / p;
+                            if (mu * r2 > 80.0) continue;
+                            double K = I.coef[ip] * J.coef[jp] * std::exp(-mu * r2) * (sign > 0 ? 2.0 * a : 1.0);
+                            double Pc[3];
+                            for (int d = 0; d < 3; d++) Pc[d] = (a * I.r[d] + b * J.r[d]) / p;
+                            double rec[8] = {p, Pc[0], Pc[1], Pc[2], Pc[0] - I.r[0], Pc[1] - I.r[1], Pc[2] - I.r[2], K};
+                            prim.insert(prim.end(), rec, rec + 8);
+                            np++;
+                        }
+                    R.nprim = np;
+                    size_t msz = (size_t)3 * (2 * I.l + 1) * (2 * J.l + 1) * ne_of(I.l + sign, J.l);
+                    if (Mbuf.size() + msz > (size_t)INT32_MAX) return fail("gradient transformation matrices exceed 2^31 doubles");
+                    R.m_off = (int)Mbuf.size();
+                    Mbuf.resize(Mbuf.size() + msz);
+                    build_M_deriv(I.l, J.l, sign, AB, c2s[I.l], c2s[J.l], Mbuf.data() + R.m_off);
+                    P.g_recs[o][sg][r] = R;
+                }
+            }
+        }
+        for (int o = 0; o < 2; o++)
+            for (int sg = 0; sg < 2; sg++)
+                if (upload(&P.d_g_recs[o][sg], P.g_recs[o][sg])) return -1;
+    }
+    if (upload(&c->d_prim, prim)) return -1;
+    if (upload(&c->d_M, Mbuf)) return -1;
+    c->grad_ready = true;
+    return 0;
+}
+
+struct GradXfArgs {
+    const PairRec *dplus, *dminus; // derivative variants of the differentiated pair (dminus may be null)
+    const PairRec *ket;            // base records of the other pair
+    const double *Mbuf;
+    const int64_t *prefix;
+    int nbra;
+    int64_t t0;
+    int swap, same_class;
+    int ne_p, ne_m, nf, ns1, ns2, nscd, nsd;
+    const double *work_p, *work_m;
+    int ncomp_p, ncomp_m;
+    const double *D; // padded
+    int ld;
+    double hyb;
+    const int *shell_atom;
+    double *grad;
+};
+
+__global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    int ib, ik;
+    find_task(A.prefix, A.nbra, A.t0 + blockIdx.x, ib, ik);
+    const bool same_pair = A.same_class && ib == ik;
+    if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
+    const PairRec dp = A.dplus[ib], cd = A.ket[ik];
+    const bool has_m = A.dminus != nullptr && A.ne_m > 0;
+    const int nsab = A.ns1 * A.ns2;
+    double *E0p = lds;                                  // [ne_p][nf]
+    double *E0m = E0p + (size_t)A.ne_p * A.nf;          // [ne_m][nf]
+    double *X = E0m + (has_m ? (size_t)A.ne_m * A.nf : 0); // [nsab][nf]
+    const double *gp = A.work_p + (size_t)blockIdx.x * A.ncomp_p;
+    for (int c = lane; c < A.ne_p * A.nf; c += 64) E0p[c] = gp[c];
+    int m_off_m = 0;
+    if (has_m) {
+        const PairRec dm = A.dminus[ib];
+        m_off_m = dm.m_off;
+        const double *gm = A.work_m + (size_t)blockIdx.x * A.ncomp_m;
+        for (int c = lane; c < A.ne_m * A.nf; c += 64) E0m[c] = gm[c];
+    }
+    __syncthreads();
+    const double *Mcd = A.Mbuf + cd.m_off;
+    double w = 4.0;
+    if (dp.sh_i == dp.sh_j) w *= 0.5;
+    if (cd.sh_i == cd.sh_j) w *= 0.5;
+    if (same_pair) w *= 0.5;
+    const double *D = A.D;
+    const int ld = A.ld;
+    for (int x = 0; x < 3; x++) {
+        const double *Mp = A.Mbuf + dp.m_off + (size_t)x * nsab * A.ne_p;
+        const double *Mm = A.Mbuf + m_off_m + (size_t)x * nsab * A.ne_m;
+        for (int o = lane; o < nsab * A.nf; o += 64) {
+            int r = o / A.nf, f = o - r * A.nf;
+            double s = 0.0;
+            for (int e = 0; e < A.ne_p; e++) s += Mp[r * A.ne_p + e] * E0p[e * A.nf + f];
+            if (has_m)
+                for (int e = 0; e < A.ne_m; e++) s += Mm[r * A.ne_m + e] * E0m[e * A.nf + f];
+            X[o] = s;
+        }
+        __syncthreads();
+        double acc = 0.0;
+        for (int o = lane; o < nsab * A.nscd; o += 64) {
+            int r = o / A.nscd, c = o - r * A.nscd;
+            double v = 0.0;
+            for (int f = 0; f < A.nf; f++) v += X[r * A.nf + f] * Mcd[c * A.nf + f];
+            int sa = r / A.ns2, sb = r - sa * A.ns2, sc = c / A.nsd, sd = c - sc * A.nsd;
+            int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
+            double G = D[(size_t)i * ld + j] * D[(size_t)k * ld + l] -
+                       0.25 * A.hyb * (D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k]);
+            acc += v * G;
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) atomicAdd(&A.grad[A.shell_atom[dp.sh_i] * 3 + x], w * acc);
+        __syncthreads();
+    }
+}
+
+extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_grad, void *stream)
+{
+    if (!c || !d_D || !d_grad) return fail("mi_grad_eri: null argument");
+    if (!c->eri_ready) return fail("mi_grad_eri: call mi_eri_prepare first");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (prepare_grad_records(c)) return -1;
+    size_t pp = (size_t)c->ldp * c->ldp;
+    hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->nao, c->ldp);
+    std::vector<int> shell_atom(c->nbas);
+    for (int i = 0; i < c->nbas; i++) shell_atom[i] = c->shells[i].atom;
+    int *d_shell_atom = nullptr;
+    if (upload(&d_shell_atom, shell_atom)) return -1;
+    const size_t WORK_DOUBLES = (size_t)16 << 20; // per buffer (plus / minus)
+    double *d_wp = nullptr, *d_wm = nullptr;
+    HIPCHK(hipMalloc(&d_wp, sizeof(double) * WORK_DOUBLES));
+    HIPCHK(hipMalloc(&d_wm, sizeof(double) * WORK_DOUBLES));
+    uint32_t *d_comp_p = nullptr, *d_comp_m = nullptr;
+    HIPCHK(hipMalloc(&d_comp_p, sizeof(uint32_t) * 16384));
+    HIPCHK(hipMalloc(&d_comp_m, sizeof(uint32_t) * 16384));
+    int64_t *d_prefix = nullptr;
+    size_t prefix_cap = 0;
+    const double tol = c->tol;
+    for (int bc = 0; bc < NPC; bc++)
+        for (int kc = 0; kc <= bc; kc++) {
+            PairClass &B = c->pc[bc], &Kc = c->pc[kc];
+            if (B.recs.empty() || Kc.recs.empty()) continue;
+            std::vector<int64_t> prefix(B.recs.size() + 1, 0);
+            for (size_t b = 0; b < B.recs.size(); b++) {
+                double thr = tol / B.q[b];
+                size_t lo = 0, hi = Kc.q.size();
+                while (lo < hi) { size_t mid = (lo + hi) / 2; if (Kc.q[mid] >= thr) lo = mid + 1; else hi = mid; }
+                int64_t cnt = (int64_t)lo;
+                if (bc == kc) cnt = std::min<int64_t>(cnt, (int64_t)b + 1);
+                prefix[b + 1] = prefix[b] + cnt;
+            }
+            int64_t ntask = prefix.back();
+            if (ntask == 0) continue;
+            if (prefix.size() > prefix_cap) {
+                if (d_prefix) hipFree(d_prefix);
+                prefix_cap = prefix.size() * 2;
+                HIPCHK(hipMalloc(&d_prefix, sizeof(int64_t) * prefix_cap));
+            }
+            HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int perm = 0; perm < 4; perm++) {
+                const bool swap = perm >= 2;
+                const int orient = perm & 1;
+                PairClass &Dc = swap ? Kc : B;   // class of the differentiated pair
+                PairClass &Oc = swap ? B : Kc;   // class of the other pair (plain ket)
+                const int l1 = orient == 0 ? Dc.la : Dc.lb, l2 = orient == 0 ? Dc.lb : Dc.la;
+                const int lc = Oc.la, ldd = Oc.lb;
+                EriArgs Ep{}, Em{};
+                setup_eri_dims(Ep, l1 + 1, l2, lc, ldd);
+                const bool has_m = l1 >= 1;
+                if (has_m) setup_eri_dims(Em, l1 - 1, l2, lc, ldd);
+                std::vector<uint32_t> comp;
+                build_comp_table(l1 + 1, l2, lc, ldd, comp);
+                if (comp.size() > 16384) return fail("component table too large");
+                HIPCHK(hipMemcpyAsync(d_comp_p, comp.data(), sizeof(uint32_t) * comp.size(), hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (has_m) {
+                    build_comp_table(l1 - 1, l2, lc, ldd, comp);
+                    HIPCHK(hipMemcpyAsync(d_comp_m, comp.data(), sizeof(uint32_t) * comp.size(), hipMemcpyHostToDevice, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                }
+                Ep.bra = Dc.d_g_recs[orient][0]; Ep.ket = Oc.d_recs; Ep.prim = c->d_prim; Ep.prefix = d_prefix; Ep.nbra = (int)B.recs.size();
+                Ep.comp = d_comp_p; Ep.work = d_wp; Ep.rys = c->rys; Ep.diag = 0; Ep.swap = swap ? 1 : 0;
+                if (has_m) {
+                    Em.bra = Dc.d_g_recs[orient][1]; Em.ket = Oc.d_recs; Em.prim = c->d_prim; Em.prefix = d_prefix; Em.nbra = Ep.nbra;
+                    Em.comp = d_comp_m; Em.work = d_wm; Em.rys = c->rys; Em.diag = 0; Em.swap = Ep.swap;
+                }
+                GradXfArgs X{};
+                X.dplus = Dc.d_g_recs[orient][0]; X.dminus = has_m ? Dc.d_g_recs[orient][1] : nullptr; X.ket = Oc.d_recs;
+                X.Mbuf = c->d_M; X.prefix = d_prefix; X.nbra = Ep.nbra; X.swap = Ep.swap; X.same_class = (bc == kc);
+                X.ne_p = ne_of(l1 + 1, l2); X.ne_m = has_m ? ne_of(l1 - 1, l2) : 0; X.nf = Oc.ne;
+                X.ns1 = 2 * l1 + 1; X.ns2 = 2 * l2 + 1; X.nscd = Oc.nsab; X.nsd = 2 * Oc.lb + 1;
+                X.work_p = d_wp; X.work_m = d_wm; X.ncomp_p = Ep.ncomp; X.ncomp_m = has_m ? Em.ncomp : 0;
+                X.D = c->d_Dpad; X.ld = c->ldp; X.hyb = hyb; X.shell_atom = d_shell_atom; X.grad = d_grad;
+                size_t shm = sizeof(double) * ((size_t)X.ne_p * X.nf + (size_t)X.ne_m * X.nf + (size_t)X.ns1 * X.ns2 * X.nf);
+                if (shm > 160 * 1024) return fail("gradient contraction needs %zu bytes of LDS", shm);
+                int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / Ep.ncomp), (int64_t)1 << 21);
+                for (int64_t t0 = 0; t0 < ntask; t0 += per) {
+                    int nb = (int)std::min<int64_t>(per, ntask - t0);
+                    Ep.t0 = t0; Ep.ntask = nb;
+                    if (launch_eri(c, Ep, nb, st)) return -1;
+                    if (has_m) { Em.t0 = t0; Em.ntask = nb; if (launch_eri(c, Em, nb, st)) return -1; }
+                    X.t0 = t0;
+                    if (shm > 64 * 1024)
+                        HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                    hipLaunchKernelGGL(eri_grad_contract, dim3(nb), dim3(64), shm, st, X);
+                    HIPCHK(hipGetLastError());
+                }
+            }
+        }
+    HIPCHK(hipStreamSynchronize(st));
+    if (d_prefix) hipFree(d_prefix);
+    hipFree(d_wp); hipFree(d_wm); hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_shell_atom);
     return 0;
 }

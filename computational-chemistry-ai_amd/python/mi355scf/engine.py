@@ -68,6 +68,7 @@ def lib():
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_grad_1e.argtypes = [vp, vp, vp, vp, vp]
+        L.mi_grad_eri.argtypes = [vp, vp, ctypes.c_double, vp, vp]
         L.mi_c2s_table.argtypes = [ctypes.c_int, dp]
         L.mi_rys_roots_host.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp]
         _lib = L
@@ -230,6 +231,11 @@ class Engine:
     # --- row a15: gradient pieces -----------------------------------------------------------------
     def grad_1e(self, D, W, grad):
         _check(lib().mi_grad_1e(self._h, D.data_ptr(), W.data_ptr(), grad.data_ptr(), self._stream()))
+
+    def grad_eri(self, D, hyb, grad):
+        if not self.eri_ready:
+            self.prepare_eri()
+        _check(lib().mi_grad_eri(self._h, D.data_ptr(), float(hyb), grad.data_ptr(), self._stream()))
 
     # --- row a11: SP2 purification helpers ------------------------------------------------------
     def sp2_init(self, f_orth, X, work):

@@ -142,6 +142,12 @@ int mi_xc_aow(mi_ctx *ctx, const double *d_ao, const double *d_wv, int64_t ng, i
  * through optimize(mf) -> mf.nuc_grad_method() (templates/optimize_geometry.py:99). */
 int mi_grad_1e(mi_ctx *ctx, const double *d_D, const double *d_W, double *d_grad, void *stream);
 
+/* d_grad[natm][3] += dE2/dR at fixed density: 2 sum (d mu nu|lam sig) [D D - hyb/4 (D D + D D)] over the
+ * Schwarz-surviving quartets, derivative ERIs by the same Rys kernel on (l+1)/(l-1) auxiliary shells.
+ * Replaces libcint int2e_ip1 + libcvhf nrs2/nrs4 J/K gradient contractions / gpu4pyscf rys gradient
+ * kernels [MEM] (mf.nuc_grad_method().get_jk). */
+int mi_grad_eri(mi_ctx *ctx, const double *d_D, double hyb, double *d_grad, void *stream);
+
 /* Real-solid-harmonic coefficient table used by the kernels: out[ncart(l)][2l+1] (host). */
 int mi_c2s_table(int l, double *out);
 
