@@ -1544,7 +1544,7 @@ struct AoArgs {
     int nbas, nao, deriv;
     const double *coords; // [ng][3]
     int64_t ng;
-    double *ao;           // [4 or 1][nao][ng]
+    double *ao;           // [1 | 4 | 10][nao][ng]: value; +gradient; +second derivatives xx,xy,xz,yy,yz,zz
 };
 
 // One thread per grid point, loop over shells (wave-uniform shell data -> scalar loads); stores are
@@ -1561,17 +1561,22 @@ __global__ __launch_bounds__(256) void eval_ao_kernel(AoArgs A)
         const double *R = A.env + A.atm[b[0] * ATM_SLOTS + 1];
         const double x = gx - R[0], y = gy - R[1], z = gz - R[2];
         const double r2 = x * x + y * y + z * z;
-        double rad = 0.0, drad = 0.0;
+        double rad = 0.0, drad = 0.0, d2rad = 0.0;
         for (int p = 0; p < np; p++) {
             double a = A.env[b[5] + p];
             double e = A.env[b[6] + p] * exp(-a * r2);
             rad += e;
             drad -= 2.0 * a * e;
+            d2rad += 4.0 * a * a * e;
         }
         const double *c2s = A.c2s + A.c2s_off[l];
         const int ns = 2 * l + 1;
-        double s[2 * LMAX + 1], sx[2 * LMAX + 1], sy[2 * LMAX + 1], sz[2 * LMAX + 1];
-        for (int m = 0; m < ns; m++) s[m] = sx[m] = sy[m] = sz[m] = 0.0;
+        double s[2 * LMAX + 1], s1[3][2 * LMAX + 1], s2[6][2 * LMAX + 1];
+        for (int m = 0; m < ns; m++) {
+            s[m] = 0.0;
+            for (int q = 0; q < 3; q++) s1[q][m] = 0.0;
+            for (int q = 0; q < 6; q++) s2[q][m] = 0.0;
+        }
         double px[LMAX + 1], py[LMAX + 1], pz[LMAX + 1];
         px[0] = py[0] = pz[0] = 1.0;
         for (int k = 1; k <= l; k++) { px[k] = px[k - 1] * x; py[k] = py[k - 1] * y; pz[k] = pz[k - 1] * z; }
@@ -1583,19 +1588,35 @@ __global__ __launch_bounds__(256) void eval_ao_kernel(AoArgs A)
                 double dx = lx ? lx * px[lx - 1] * py[ly] * pz[lz] : 0.0;
                 double dy = ly ? ly * px[lx] * py[ly - 1] * pz[lz] : 0.0;
                 double dz = lz ? lz * px[lx] * py[ly] * pz[lz - 1] : 0.0;
+                double h2[6] = {0, 0, 0, 0, 0, 0};
+                if (A.deriv >= 2) {
+                    h2[0] = lx > 1 ? lx * (lx - 1) * px[lx - 2] * py[ly] * pz[lz] : 0.0;
+                    h2[1] = (lx && ly) ? lx * ly * px[lx - 1] * py[ly - 1] * pz[lz] : 0.0;
+                    h2[2] = (lx && lz) ? lx * lz * px[lx - 1] * py[ly] * pz[lz - 1] : 0.0;
+                    h2[3] = ly > 1 ? ly * (ly - 1) * px[lx] * py[ly - 2] * pz[lz] : 0.0;
+                    h2[4] = (ly && lz) ? ly * lz * px[lx] * py[ly - 1] * pz[lz - 1] : 0.0;
+                    h2[5] = lz > 1 ? lz * (lz - 1) * px[lx] * py[ly] * pz[lz - 2] : 0.0;
+                }
                 for (int m = 0; m < ns; m++) {
                     double cc = c2s[k * ns + m];
-                    s[m] += cc * v; sx[m] += cc * dx; sy[m] += cc * dy; sz[m] += cc * dz;
+                    s[m] += cc * v; s1[0][m] += cc * dx; s1[1][m] += cc * dy; s1[2][m] += cc * dz;
+                    if (A.deriv >= 2)
+                        for (int q = 0; q < 6; q++) s2[q][m] += cc * h2[q];
                 }
             }
         const int ao0 = A.shell_ao[ish];
+        const double xyz[3] = {x, y, z};
         for (int m = 0; m < ns; m++) {
             size_t o = (size_t)(ao0 + m) * A.ng + g;
             A.ao[o] = rad * s[m];
-            if (A.deriv) {
-                A.ao[comp + o] = drad * x * s[m] + rad * sx[m];
-                A.ao[2 * comp + o] = drad * y * s[m] + rad * sy[m];
-                A.ao[3 * comp + o] = drad * z * s[m] + rad * sz[m];
+            if (A.deriv >= 1)
+                for (int q = 0; q < 3; q++) A.ao[(1 + q) * comp + o] = drad * xyz[q] * s[m] + rad * s1[q][m];
+            if (A.deriv >= 2) {
+                int q = 0;
+                for (int i = 0; i < 3; i++)
+                    for (int j = i; j < 3; j++, q++)
+                        A.ao[(4 + q) * comp + o] = d2rad * xyz[i] * xyz[j] * s[m] + (i == j ? drad * s[m] : 0.0) +
+                                                   drad * (xyz[i] * s1[j][m] + xyz[j] * s1[i][m]) + rad * s2[q][m];
             }
         }
     }

@@ -198,7 +198,7 @@ class Engine:
     def eval_ao(self, coords, deriv=1, out=None):
         ng = coords.shape[0]
         if out is None:
-            out = self._new(4 if deriv else 1, self.nao, ng)
+            out = self._new({0: 1, 1: 4, 2: 10}[int(deriv)], self.nao, ng)
         _check(lib().mi_eval_ao(self._h, coords.data_ptr(), ng, int(deriv), out.data_ptr(), self._stream()))
         return out
 

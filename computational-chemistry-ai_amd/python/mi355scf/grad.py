@@ -1,17 +1,113 @@
 """Nuclear gradients behind `mf.nuc_grad_method()` (used by `optimize`,
 `templates/optimize_geometry.py:99`).
 
-Round-1 status: the analytic derivative-integral kernels are not built yet; `Gradients.kernel()`
-evaluates dE/dR by CENTRAL FINITE DIFFERENCES of the GPU SCF energy (warm-started from the converged
-density, 6 N_atom SCF runs).  It is exact to O(h^2) and serves as the check for the analytic path of
-the next round; it is far too slow for ibuprofen-sized systems (BASELINE config 5).
+`Gradients` is analytic: dE/dR = 1e term (`mi_grad_1e`: D.dh - W.dS + Hellmann-Feynman) + 2e term
+(`mi_grad_eri`: derivative ERIs contracted with the two-particle density) + XC term (HIP AO second
+derivatives + device contractions, no grid-weight response, as PySCF's default `grid_response=False` [MEM])
++ nuclear repulsion.  `FDGradients` (central finite differences of the SCF energy) is kept as the
+independent check used by the tests.
 """
 import numpy as np
+import torch
 
 from .mole import Mole
 
 
+def grad_nuc(mol):
+    z = mol.atom_charges().astype(np.float64)
+    R = mol.atom_coords()
+    g = np.zeros_like(R)
+    for i in range(mol.natm):
+        for j in range(mol.natm):
+            if i != j:
+                d = R[i] - R[j]
+                g[i] -= z[i] * z[j] * d / np.linalg.norm(d) ** 3
+    return g
+
+
 class Gradients:
+    """Analytic RHF/RKS gradient on the MI355X engine."""
+
+    def __init__(self, mf):
+        self.base = mf
+        self.mol = mf.mol
+        self.de = None
+        self.verbose = mf.verbose
+
+    def grad_xc(self, dm):
+        """-2 sum_{mu on A} D_mu,nu int [v_rho dphi_mu phi_nu + 2 v_sigma grad rho . grad(dphi_mu phi_nu)]"""
+        from .dft import parse_xc
+        mf = self.base
+        eng = mf.engine
+        hyb, terms, gga = parse_xc(mf.xc)
+        n = eng.nao
+        coords, weights = mf.grids.coords, mf.grids.weights
+        lo, hi = mf._grid_range(coords.shape[0])
+        fmu = torch.zeros(n, 3, dtype=torch.float64, device=eng.device)
+        B = max(4096, mf.grid_block // 4)
+        pair = {(0, 0): 4, (0, 1): 5, (0, 2): 6, (1, 1): 7, (1, 2): 8, (2, 2): 9}
+        for p0 in range(lo, hi, B):
+            p1 = min(p0 + B, hi)
+            c, w = coords[p0:p1], weights[p0:p1]
+            ao = eng.eval_ao(c, deriv=2 if gga else 1)
+            C = dm @ ao[0]
+            rho = eng.xc_rho(ao, C, deriv=1 if gga else 0)
+            _e, wv = eng.xc_eval(terms, rho, w, gga)
+            if gga:
+                T1 = 2.0 * wv[0] * C
+                for j in range(3):
+                    T1 += wv[1 + j] * (dm @ ao[1 + j])
+                for k in range(3):
+                    t2 = sum(wv[1 + j] * ao[pair[(min(j, k), max(j, k))]] for j in range(3))
+                    fmu[:, k] += -2.0 * ((ao[1 + k] * T1).sum(dim=1) + (t2 * C).sum(dim=1))
+            else:
+                T1 = 2.0 * wv[0] * C
+                for k in range(3):
+                    fmu[:, k] += -2.0 * (ao[1 + k] * T1).sum(dim=1)
+        if mf._nranks > 1:
+            from . import parallel
+            parallel.all_reduce_sum(fmu, mf._pg)
+        f = fmu.cpu().numpy()
+        sl = mf.mol.aoslice_by_atom()
+        return np.array([f[sl[ia, 2]:sl[ia, 3]].sum(axis=0) for ia in range(mf.mol.natm)])
+
+    def kernel(self, mo_energy=None, mo_coeff=None, mo_occ=None, atmlst=None):
+        mf = self.base
+        if mf._dm is None or not mf.converged:
+            mf.kernel()
+        eng = mf.engine
+        mol = mf.mol
+        dm = mf._dm
+        fock = mf._h1 + mf._vhf
+        W = 0.5 * dm @ fock @ dm
+        g = torch.zeros(mol.natm, 3, dtype=torch.float64, device=eng.device)
+        eng.grad_1e(dm.contiguous(), W.contiguous(), g)
+        is_ks = getattr(mf, "xc", None) is not None and hasattr(mf, "grids")
+        hyb = 1.0
+        if is_ks:
+            from .dft import parse_xc
+            hyb = parse_xc(mf.xc)[0]
+        g2 = torch.zeros_like(g)
+        eng.grad_eri(dm.contiguous(), hyb, g2)
+        if mf._nranks > 1:   # every rank evaluates all quartets (not sharded yet): no reduction needed
+            pass
+        de = (g + g2).cpu().numpy() + grad_nuc(mol)
+        if is_ks:
+            de = de + self.grad_xc(dm)
+        self.de = de
+        if self.verbose >= 4:
+            mf._log(4, "--------------- gradients ---------------")
+            for ia in range(mol.natm):
+                mf._log(4, "%d %s  %16.10f %16.10f %16.10f" % (ia, mol.atom_pure_symbol(ia), *de[ia]))
+        return de
+
+    grad = kernel
+
+    def as_scanner(self):
+        return _GradScanner(self)
+
+
+class FDGradients:
     step = 2.0e-3  # Bohr
 
     def __init__(self, mf):
@@ -54,7 +150,7 @@ class Gradients:
                 Rm[ia, x] -= h
                 g[ia, x] = (self._energy_at(Rp, dm0) - self._energy_at(Rm, dm0)) / (2 * h)
         self.de = g
-        if self.verbose >= 4:
+        if self.verbose >= 5:
             mf._log(4, "--------------- gradients (finite difference) ---------------")
             for ia in range(mf.mol.natm):
                 mf._log(4, "%d %s  %16.10f %16.10f %16.10f" % (ia, mf.mol.atom_pure_symbol(ia), *g[ia]))

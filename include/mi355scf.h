@@ -116,7 +116,8 @@ int mi_sp2_update(mi_ctx *ctx, double *d_X, const double *d_X2, double n_occ, do
 int mi_grid_becke(mi_ctx *ctx, const double *d_coords, const int32_t *d_atom_of, const double *d_vol,
                   int64_t ng, const double *d_adjust, double *d_weights, void *stream);
 
-/* AO values (deriv=0) or values+gradient (deriv=1) on grid points: d_ao[(1|4)][nao][ng].
+/* AO values (deriv=0), +gradient (deriv=1), +second derivatives xx,xy,xz,yy,yz,zz (deriv=2, for the XC
+ * nuclear gradient) on grid points: d_ao[(1|4|10)][nao][ng].
  * Replaces libdft GTOval_sph_deriv1 / gpu4pyscf GDFTeval_gto [MEM] (numint.eval_ao). */
 int mi_eval_ao(mi_ctx *ctx, const double *d_coords, int64_t ng, int deriv, double *d_ao, void *stream);
 

@@ -72,3 +72,75 @@ def test_grad_eri_matches_finite_difference(name, basis, hyb):
     ref = _fd(mol, f)
     assert np.abs(g - ref).max() < 5e-6 * max(1.0, np.abs(ref).max()), (g, ref)
     assert np.abs(g.sum(axis=0)).max() < 1e-8 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name,basis,method", [("h2o", "cc-pvdz", "HF"), ("h2co", "6-31g(d)", "HF"), ("h2o", "cc-pvtz", "HF")])
+def test_total_rhf_gradient_matches_finite_difference(name, basis, method):
+    from pyscf import gto, scf
+    from mi355scf.grad import FDGradients
+    mol = gto.Mole()
+    mol.atom = MOLECULES[name]
+    mol.basis = basis
+    mol.verbose = 0
+    mol.build()
+    mf = scf.RHF(mol)
+    mf.conv_tol = 1e-11
+    mf.kernel()
+    g = mf.nuc_grad_method().kernel()
+    fd = FDGradients(mf)
+    fd.step = 5e-4
+    ref = fd.kernel()
+    assert np.abs(g - ref).max() < 1e-6, (g, ref)
+    assert np.abs(g.sum(axis=0)).max() < 1e-7
+
+
+@pytest.mark.parametrize("xc", ["LDA,VWN", "B3LYP", "PBE"])
+def test_xc_gradient_matches_frozen_weight_finite_difference(xc):
+    """d/dR of E_xc[D] on a grid FROZEN in space (points and weights) while the basis functions move ==
+    the analytic XC gradient without grid response (what PySCF computes by default [MEM])."""
+    from pyscf import gto, dft
+    mol = gto.Mole()
+    mol.atom = MOLECULES["h2o"]
+    mol.basis = "cc-pvdz"
+    mol.verbose = 0
+    mol.build()
+    mf = dft.RKS(mol)
+    mf.xc = xc
+    mf.kernel()
+    dm = mf._dm
+    g = mf.nuc_grad_method().grad_xc(dm)
+    coords0, w0, owner = mf.grids.coords.clone(), mf.grids.weights.clone(), mf.grids.atom_of
+    R = mol.atom_coords()
+    ref = np.zeros_like(R)
+    for ia in range(mol.natm):
+        for x in range(3):
+            vals = []
+            for sgn in (+1, -1):
+                Rn = R.copy()
+                Rn[ia, x] += sgn * H
+                m2 = mol.set_geom_(Rn, unit="Bohr", inplace=False)
+                mf2 = dft.RKS(m2)
+                mf2.xc = xc
+                mf2._setup_once()
+                mf2.grids.coords, mf2.grids.weights = coords0, w0
+                vals.append(float(mf2.nr_rks(dm)[1]))
+            ref[ia, x] = (vals[0] - vals[1]) / (2 * H)
+    assert np.abs(g - ref).max() < 2e-6, (g, ref)
+
+
+def test_total_b3lyp_gradient_close_to_finite_difference():
+    """Total RKS gradient vs full finite differences; the difference is the neglected grid-weight response."""
+    from pyscf import gto, dft
+    from mi355scf.grad import FDGradients
+    mol = gto.Mole()
+    mol.atom = MOLECULES["h2o"]
+    mol.basis = "6-31g(d)"
+    mol.verbose = 0
+    mol.build()
+    mf = dft.RKS(mol)
+    mf.xc = "B3LYP"
+    mf.conv_tol = 1e-11
+    mf.kernel()
+    g = mf.nuc_grad_method().kernel()
+    ref = FDGradients(mf).kernel()
+    assert np.abs(g - ref).max() < 2e-4, (g, ref)
