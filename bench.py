@@ -107,8 +107,18 @@ def main():
     n = mol.nao
     alg_bytes = 8.0 * stats["n_unique_eri"] + 24.0 * n * n
     achieved = alg_bytes / (ms * 1e-3) / 1e9
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+    # profiles/r01_pmc_jk_traffic.json -- not re-measured here (PMC needs the profiler); null for other workloads
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_jk_traffic.json")))
+        case = pmc["cases"].get("benzene/" + args.basis)
+        if case and world == 1 and abs(case["algorithmic_bytes"] - alg_bytes) < 1e-6 * alg_bytes:
+            traffic = case["traffic_bytes"]
+    except Exception:
+        traffic = None
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": "jk_tiles_kernel<true,true>", "ms_per_launch": ms,
+            "traffic": traffic, "kernel": "jk_tiles_kernel<true,true,true>", "ms_per_launch": ms,
             "algorithmic_bytes": alg_bytes, "stored_bytes": stats["stored_bytes"],
             "stored_GBps": stats["stored_bytes"] / (ms * 1e-3) / 1e9}
 
