@@ -49,6 +49,19 @@ static int fail(const char *fmt, ...)
     } while (0)
 
 extern "C" const char *mi_last_error(void) { return g_err.c_str(); }
+
+// Host-side OpenMP is used only for the per-pair transformation matrices.  Idle workers must not spin
+// (libomp's default 200 ms block time starves the Python/torch threads between calls).
+static int host_threads()
+{
+    static int n = [] {
+        setenv("KMP_BLOCKTIME", "0", 0);
+        const char *e = getenv("MI355_HOST_THREADS");
+        int v = e ? atoi(e) : 16;
+        return v < 1 ? 1 : v;
+    }();
+    return n;
+}
 extern "C" int mi_abi_version(void) { return 1; }
 
 // =================================================================================================
@@ -212,6 +225,7 @@ struct mi_ctx {
     double *d_M = nullptr;               // all transformation matrices
     std::vector<double> h_prim, h_M;     // host copies (gradient variants are appended lazily)
     double tol = 1e-13;
+    int rank = 0, nranks = 1;
     bool grad_ready = false;
     // component index tables per class quadruple (built lazily)
     // tiles
@@ -866,7 +880,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     // ---- 1. shell pairs, primitive-pair records, transformation matrices
     std::vector<double> &prim = c->h_prim, &Mbuf = c->h_M;
     prim.clear(); Mbuf.clear();
-    c->tol = tol; c->grad_ready = false;
+    c->tol = tol; c->grad_ready = false; c->rank = rank; c->nranks = nranks;
     for (int la = 0; la <= LMAX; la++)
         for (int lb = 0; lb <= la; lb++) {
             PairClass &P = c->pc[pc_index(la, lb)];
@@ -899,9 +913,19 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             R.nprim = np;
             R.m_off = (int)Mbuf.size();
             Mbuf.resize(Mbuf.size() + (size_t)P.nsab * P.ne);
-            build_M(I.l, J.l, AB, c2s[I.l], c2s[J.l], Mbuf.data() + R.m_off);
             P.recs.push_back(R);
         }
+    {   // HRR*c2s matrices of all pairs (OpenMP: this is the costly host part of the setup)
+        std::vector<const PairRec *> all;
+        for (int ci = 0; ci < NPC; ci++)
+            for (const PairRec &R : c->pc[ci].recs) all.push_back(&R);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(host_threads())
+        for (size_t q = 0; q < all.size(); q++) {
+            const ShellH &I = c->shells[all[q]->sh_i], &J = c->shells[all[q]->sh_j];
+            double AB[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+            build_M(I.l, J.l, AB, c2s[I.l], c2s[J.l], Mbuf.data() + all[q]->m_off);
+        }
+    }
     if (Mbuf.size() > (size_t)INT32_MAX) return fail("transformation-matrix buffer exceeds 2^31 doubles");
     if (upload(&c->d_prim, prim)) return -1;
     if (upload(&c->d_M, Mbuf)) return -1;
@@ -2140,48 +2164,70 @@ static int prepare_grad_records(mi_ctx *c)
     std::vector<std::vector<double>> c2s(LMAX + 1);
     for (int l = 0; l <= LMAX; l++) c2s_generic(l, c2s[l]);
     std::vector<double> &prim = c->h_prim, &Mbuf = c->h_M;
+    // pass 1 (serial, cheap): sizes and offsets of every variant record
+    struct Job { int ci, r, o, sg; };
+    std::vector<Job> jobs;
+    size_t prim_end = prim.size() / 8, m_end = Mbuf.size();
     for (int ci = 0; ci < NPC; ci++) {
         PairClass &P = c->pc[ci];
         for (int o = 0; o < 2; o++)
             for (int sg = 0; sg < 2; sg++) P.g_recs[o][sg].assign(P.recs.size(), PairRec{-1, -1, 0, 0, 0, 0, 0, 0});
-        for (size_t r = 0; r < P.recs.size(); r++) {
+        for (size_t r = 0; r < P.recs.size(); r++)
             for (int o = 0; o < 2; o++) {
                 int s1 = o == 0 ? P.recs[r].sh_i : P.recs[r].sh_j, s2 = o == 0 ? P.recs[r].sh_j : P.recs[r].sh_i;
                 const ShellH &I = c->shells[s1], &J = c->shells[s2];
-                double AB[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
-                double r2 = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
+                double r2 = 0.0;
+                for (int d = 0; d < 3; d++) r2 += (I.r[d] - J.r[d]) * (I.r[d] - J.r[d]);
+                int np = 0;
+                for (int ip = 0; ip < I.nprim; ip++)
+                    for (int jp = 0; jp < J.nprim; jp++)
+                        if (I.exps[ip] * J.exps[jp] / (I.exps[ip] + J.exps[jp]) * r2 <= 80.0) np++;
                 for (int sg = 0; sg < 2; sg++) {
                     int sign = sg == 0 ? +1 : -1;
                     if (I.l + sign < 0) continue;
                     PairRec R;
                     R.sh_i = s1; R.sh_j = s2; R.ao_i = I.ao; R.ao_j = J.ao; R.pad = 0;
-                    R.prim_off = (int)(prim.size() / 8);
-                    int np = 0;
-                    for (int ip = 0; ip < I.nprim; ip++)
-                        for (int jp = 0; jp < J.nprim; jp++) {
-                            double a = I.exps[ip], b = J.exps[jp], p = a + b, mu = a * b / p;
-                            if (mu * r2 > 80.0) continue;
-                            double K = I.coef[ip] * J.coef[jp] * std::exp(-mu * r2) * (sign > 0 ? 2.0 * a : 1.0);
-                            double Pc[3];
-                            for (int d = 0; d < 3; d++) Pc[d] = (a * I.r[d] + b * J.r[d]) / p;
-                            double rec[8] = {p, Pc[0], Pc[1], Pc[2], Pc[0] - I.r[0], Pc[1] - I.r[1], Pc[2] - I.r[2], K};
-                            prim.insert(prim.end(), rec, rec + 8);
-                            np++;
-                        }
-                    R.nprim = np;
+                    R.prim_off = (int)prim_end; R.nprim = np;
+                    prim_end += np;
                     size_t msz = (size_t)3 * (2 * I.l + 1) * (2 * J.l + 1) * ne_of(I.l + sign, J.l);
-                    if (Mbuf.size() + msz > (size_t)INT32_MAX) return fail("gradient transformation matrices exceed 2^31 doubles");
-                    R.m_off = (int)Mbuf.size();
-                    Mbuf.resize(Mbuf.size() + msz);
-                    build_M_deriv(I.l, J.l, sign, AB, c2s[I.l], c2s[J.l], Mbuf.data() + R.m_off);
+                    if (m_end + msz > (size_t)INT32_MAX) return fail("gradient transformation matrices exceed 2^31 doubles");
+                    R.m_off = (int)m_end;
+                    m_end += msz;
                     P.g_recs[o][sg][r] = R;
+                    jobs.push_back({ci, (int)r, o, sg});
                 }
             }
-        }
+    }
+    prim.resize(prim_end * 8);
+    Mbuf.resize(m_end);
+    // pass 2 (OpenMP): fill primitive records and HRR*derivative*c2s matrices
+#pragma omp parallel for schedule(dynamic, 64) num_threads(host_threads())
+    for (size_t q = 0; q < jobs.size(); q++) {
+        const Job jb = jobs[q];
+        PairClass &P = c->pc[jb.ci];
+        const PairRec &R = P.g_recs[jb.o][jb.sg][jb.r];
+        const ShellH &I = c->shells[R.sh_i], &J = c->shells[R.sh_j];
+        const int sign = jb.sg == 0 ? +1 : -1;
+        double AB[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+        double r2 = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
+        double *dst = prim.data() + (size_t)R.prim_off * 8;
+        for (int ip = 0; ip < I.nprim; ip++)
+            for (int jp = 0; jp < J.nprim; jp++) {
+                double a = I.exps[ip], b = J.exps[jp], p = a + b, mu = a * b / p;
+                if (mu * r2 > 80.0) continue;
+                double K = I.coef[ip] * J.coef[jp] * std::exp(-mu * r2) * (sign > 0 ? 2.0 * a : 1.0);
+                double Pc[3];
+                for (int d = 0; d < 3; d++) Pc[d] = (a * I.r[d] + b * J.r[d]) / p;
+                double rec[8] = {p, Pc[0], Pc[1], Pc[2], Pc[0] - I.r[0], Pc[1] - I.r[1], Pc[2] - I.r[2], K};
+                memcpy(dst, rec, sizeof rec);
+                dst += 8;
+            }
+        build_M_deriv(I.l, J.l, sign, AB, c2s[I.l], c2s[J.l], Mbuf.data() + R.m_off);
+    }
+    for (int ci = 0; ci < NPC; ci++)
         for (int o = 0; o < 2; o++)
             for (int sg = 0; sg < 2; sg++)
-                if (upload(&P.d_g_recs[o][sg], P.g_recs[o][sg])) return -1;
-    }
+                if (upload(&c->pc[ci].d_g_recs[o][sg], c->pc[ci].g_recs[o][sg])) return -1;
     if (upload(&c->d_prim, prim)) return -1;
     if (upload(&c->d_M, Mbuf)) return -1;
     c->grad_ready = true;
@@ -2204,10 +2250,16 @@ struct GradXfArgs {
     double hyb;
     const int *shell_atom;
     double *grad;
+    int inv_from_second; // translational invariance: 1: the skipped shell is dp.sh_j, 0: it is cd.sh_i
+    int natm3;           // grad points to GRAD_COPIES private copies of [natm*3] (atomic contention relief)
 };
+#define GRAD_COPIES 4096
 
 __global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
 {
+    // sum_{x-independent part first}:  g[x] = sum_{r,e} M^x[r][e] * Z[r][e],  Z[r][e] = sum_f E0[e][f] Y[r][f],
+    // Y[r][f] = sum_c G[r][c] Mcd[c][f]  -- contracting the two-particle density FIRST makes the work
+    // independent of the derivative direction (3x fewer flops than forming the derivative integrals).
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     int ib, ik;
@@ -2216,54 +2268,82 @@ __global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
     if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec dp = A.dplus[ib], cd = A.ket[ik];
     const bool has_m = A.dminus != nullptr && A.ne_m > 0;
-    const int nsab = A.ns1 * A.ns2;
-    double *E0p = lds;                                  // [ne_p][nf]
-    double *E0m = E0p + (size_t)A.ne_p * A.nf;          // [ne_m][nf]
-    double *X = E0m + (has_m ? (size_t)A.ne_m * A.nf : 0); // [nsab][nf]
+    const int nsab = A.ns1 * A.ns2, nf = A.nf;
+    double *E0p = lds;                                        // [ne_p][nf]
+    double *E0m = E0p + (size_t)A.ne_p * nf;                  // [ne_m][nf]
+    double *G = E0m + (has_m ? (size_t)A.ne_m * nf : 0);      // [nsab][nscd]
+    double *Y = G + (size_t)nsab * A.nscd;                    // [nsab][nf]
     const double *gp = A.work_p + (size_t)blockIdx.x * A.ncomp_p;
-    for (int c = lane; c < A.ne_p * A.nf; c += 64) E0p[c] = gp[c];
+    for (int c = lane; c < A.ne_p * nf; c += 64) E0p[c] = gp[c];
     int m_off_m = 0;
     if (has_m) {
         const PairRec dm = A.dminus[ib];
         m_off_m = dm.m_off;
         const double *gm = A.work_m + (size_t)blockIdx.x * A.ncomp_m;
-        for (int c = lane; c < A.ne_m * A.nf; c += 64) E0m[c] = gm[c];
+        for (int c = lane; c < A.ne_m * nf; c += 64) E0m[c] = gm[c];
+    }
+    const double *D = A.D;
+    const int ld = A.ld;
+    for (int o = lane; o < nsab * A.nscd; o += 64) {
+        int r = o / A.nscd, c = o - r * A.nscd;
+        int sa = r / A.ns2, sb = r - sa * A.ns2, sc = c / A.nsd, sd = c - sc * A.nsd;
+        int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
+        G[o] = D[(size_t)i * ld + j] * D[(size_t)k * ld + l] -
+               0.25 * A.hyb * (D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k]);
     }
     __syncthreads();
     const double *Mcd = A.Mbuf + cd.m_off;
+    for (int o = lane; o < nsab * nf; o += 64) {
+        int r = o / nf, f = o - r * nf;
+        double s = 0.0;
+        for (int c = 0; c < A.nscd; c++) s += G[r * A.nscd + c] * Mcd[c * nf + f];
+        Y[o] = s;
+    }
+    __syncthreads();
+    double acc[3] = {0.0, 0.0, 0.0};
+    {
+        const double *Mp = A.Mbuf + dp.m_off;
+        const size_t xs = (size_t)nsab * A.ne_p;
+        for (int o = lane; o < nsab * A.ne_p; o += 64) {
+            int r = o / A.ne_p, e = o - r * A.ne_p;
+            double z = 0.0;
+            for (int f = 0; f < nf; f++) z += E0p[e * nf + f] * Y[r * nf + f];
+            acc[0] += Mp[o] * z; acc[1] += Mp[xs + o] * z; acc[2] += Mp[2 * xs + o] * z;
+        }
+    }
+    if (has_m) {
+        const double *Mm = A.Mbuf + m_off_m;
+        const size_t xs = (size_t)nsab * A.ne_m;
+        for (int o = lane; o < nsab * A.ne_m; o += 64) {
+            int r = o / A.ne_m, e = o - r * A.ne_m;
+            double z = 0.0;
+            for (int f = 0; f < nf; f++) z += E0m[e * nf + f] * Y[r * nf + f];
+            acc[0] += Mm[o] * z; acc[1] += Mm[xs + o] * z; acc[2] += Mm[2 * xs + o] * z;
+        }
+    }
     double w = 4.0;
     if (dp.sh_i == dp.sh_j) w *= 0.5;
     if (cd.sh_i == cd.sh_j) w *= 0.5;
     if (same_pair) w *= 0.5;
-    const double *D = A.D;
-    const int ld = A.ld;
     for (int x = 0; x < 3; x++) {
-        const double *Mp = A.Mbuf + dp.m_off + (size_t)x * nsab * A.ne_p;
-        const double *Mm = A.Mbuf + m_off_m + (size_t)x * nsab * A.ne_m;
-        for (int o = lane; o < nsab * A.nf; o += 64) {
-            int r = o / A.nf, f = o - r * A.nf;
-            double s = 0.0;
-            for (int e = 0; e < A.ne_p; e++) s += Mp[r * A.ne_p + e] * E0p[e * A.nf + f];
-            if (has_m)
-                for (int e = 0; e < A.ne_m; e++) s += Mm[r * A.ne_m + e] * E0m[e * A.nf + f];
-            X[o] = s;
+        double v = acc[x];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) {
+            double *gc = A.grad + (size_t)(blockIdx.x & (GRAD_COPIES - 1)) * A.natm3;
+            atomicAdd(&gc[A.shell_atom[dp.sh_i] * 3 + x], w * v);
+            // the skipped permutation (derivative on the first shell of the bra pair P) by invariance
+            atomicAdd(&gc[A.shell_atom[A.inv_from_second ? dp.sh_j : cd.sh_i] * 3 + x], -w * v);
         }
-        __syncthreads();
-        double acc = 0.0;
-        for (int o = lane; o < nsab * A.nscd; o += 64) {
-            int r = o / A.nscd, c = o - r * A.nscd;
-            double v = 0.0;
-            for (int f = 0; f < A.nf; f++) v += X[r * A.nf + f] * Mcd[c * A.nf + f];
-            int sa = r / A.ns2, sb = r - sa * A.ns2, sc = c / A.nsd, sd = c - sc * A.nsd;
-            int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
-            double G = D[(size_t)i * ld + j] * D[(size_t)k * ld + l] -
-                       0.25 * A.hyb * (D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k]);
-            acc += v * G;
-        }
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) atomicAdd(&A.grad[A.shell_atom[dp.sh_i] * 3 + x], w * acc);
-        __syncthreads();
     }
+}
+
+__global__ void grad_reduce_copies_kernel(const double *copies, int natm3, double *grad)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= natm3) return;
+    double s = 0.0;
+    for (int c = 0; c < GRAD_COPIES; c++) s += copies[(size_t)c * natm3 + idx];
+    grad[idx] += s;
 }
 
 extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_grad, void *stream)
@@ -2272,13 +2352,19 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
     if (!c->eri_ready) return fail("mi_grad_eri: call mi_eri_prepare first");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
+    auto tg0 = std::chrono::steady_clock::now();
     if (prepare_grad_records(c)) return -1;
+    auto tg1 = std::chrono::steady_clock::now();
     size_t pp = (size_t)c->ldp * c->ldp;
     hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->nao, c->ldp);
     std::vector<int> shell_atom(c->nbas);
     for (int i = 0; i < c->nbas; i++) shell_atom[i] = c->shells[i].atom;
     int *d_shell_atom = nullptr;
     if (upload(&d_shell_atom, shell_atom)) return -1;
+    const int natm3 = c->natm * 3;
+    double *d_gcopies = nullptr;
+    HIPCHK(hipMalloc(&d_gcopies, sizeof(double) * (size_t)GRAD_COPIES * natm3));
+    HIPCHK(hipMemsetAsync(d_gcopies, 0, sizeof(double) * (size_t)GRAD_COPIES * natm3, st));
     const size_t WORK_DOUBLES = (size_t)16 << 20; // per buffer (plus / minus)
     double *d_wp = nullptr, *d_wm = nullptr;
     HIPCHK(hipMalloc(&d_wp, sizeof(double) * WORK_DOUBLES));
@@ -2289,6 +2375,7 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
     int64_t *d_prefix = nullptr;
     size_t prefix_cap = 0;
     const double tol = c->tol;
+    int64_t batch_counter = 0;
     for (int bc = 0; bc < NPC; bc++)
         for (int kc = 0; kc <= bc; kc++) {
             PairClass &B = c->pc[bc], &Kc = c->pc[kc];
@@ -2311,7 +2398,8 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
             }
             HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st));
-            for (int perm = 0; perm < 4; perm++) {
+            // perm 0 (derivative on P.sh_i, the costliest: highest l) is skipped: sum of the four forces = 0
+            for (int perm = 1; perm < 4; perm++) {
                 const bool swap = perm >= 2;
                 const int orient = perm & 1;
                 PairClass &Dc = swap ? Kc : B;   // class of the differentiated pair
@@ -2344,11 +2432,14 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                 X.ne_p = ne_of(l1 + 1, l2); X.ne_m = has_m ? ne_of(l1 - 1, l2) : 0; X.nf = Oc.ne;
                 X.ns1 = 2 * l1 + 1; X.ns2 = 2 * l2 + 1; X.nscd = Oc.nsab; X.nsd = 2 * Oc.lb + 1;
                 X.work_p = d_wp; X.work_m = d_wm; X.ncomp_p = Ep.ncomp; X.ncomp_m = has_m ? Em.ncomp : 0;
-                X.D = c->d_Dpad; X.ld = c->ldp; X.hyb = hyb; X.shell_atom = d_shell_atom; X.grad = d_grad;
-                size_t shm = sizeof(double) * ((size_t)X.ne_p * X.nf + (size_t)X.ne_m * X.nf + (size_t)X.ns1 * X.ns2 * X.nf);
+                X.D = c->d_Dpad; X.ld = c->ldp; X.hyb = hyb; X.shell_atom = d_shell_atom; X.grad = d_gcopies; X.natm3 = natm3;
+                X.inv_from_second = swap ? 0 : 1;
+                size_t shm = sizeof(double) * ((size_t)X.ne_p * X.nf + (size_t)X.ne_m * X.nf + (size_t)X.ns1 * X.ns2 * (X.nf + X.nscd));
                 if (shm > 160 * 1024) return fail("gradient contraction needs %zu bytes of LDS", shm);
                 int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / Ep.ncomp), (int64_t)1 << 21);
+                if (c->nranks > 1) per = std::min<int64_t>(per, std::max<int64_t>(1024, ntask / (8 * c->nranks)));
                 for (int64_t t0 = 0; t0 < ntask; t0 += per) {
+                    if ((int)((batch_counter++) % c->nranks) != c->rank) continue; // batches dealt round-robin to ranks
                     int nb = (int)std::min<int64_t>(per, ntask - t0);
                     Ep.t0 = t0; Ep.ntask = nb;
                     if (launch_eri(c, Ep, nb, st)) return -1;
@@ -2361,7 +2452,13 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                 }
             }
         }
+    hipLaunchKernelGGL(grad_reduce_copies_kernel, dim3((natm3 + 63) / 64), dim3(64), 0, st, d_gcopies, natm3, d_grad);
     HIPCHK(hipStreamSynchronize(st));
+    hipFree(d_gcopies);
+    if (getenv("MI355_DEBUG"))
+        fprintf(stderr, "[mi355] grad_eri: variant records %.3f s, derivative quartets %.3f s\n",
+                std::chrono::duration<double>(tg1 - tg0).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count());
     if (d_prefix) hipFree(d_prefix);
     hipFree(d_wp); hipFree(d_wm); hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_shell_atom);
     return 0;

@@ -80,20 +80,33 @@ class Gradients:
         dm = mf._dm
         fock = mf._h1 + mf._vhf
         W = 0.5 * dm @ fock @ dm
+        import time
+        tm = {}
+        t0 = time.time()
         g = torch.zeros(mol.natm, 3, dtype=torch.float64, device=eng.device)
         eng.grad_1e(dm.contiguous(), W.contiguous(), g)
+        torch.cuda.synchronize()
+        tm["grad_1e"] = time.time() - t0
         is_ks = getattr(mf, "xc", None) is not None and hasattr(mf, "grids")
         hyb = 1.0
         if is_ks:
             from .dft import parse_xc
             hyb = parse_xc(mf.xc)[0]
+        t0 = time.time()
         g2 = torch.zeros_like(g)
         eng.grad_eri(dm.contiguous(), hyb, g2)
-        if mf._nranks > 1:   # every rank evaluates all quartets (not sharded yet): no reduction needed
-            pass
+        tm["grad_eri"] = time.time() - t0
+        if mf._nranks > 1:   # derivative-quartet batches are dealt round-robin to ranks inside mi_grad_eri
+            from . import parallel
+            parallel.all_reduce_sum(g2, mf._pg)
         de = (g + g2).cpu().numpy() + grad_nuc(mol)
         if is_ks:
+            t0 = time.time()
             de = de + self.grad_xc(dm)
+            torch.cuda.synchronize()
+            tm["grad_xc"] = time.time() - t0
+        self.timing = tm
+        mf._log(4, "gradient timings (s): " + ", ".join(f"{k} {v:.3f}" for k, v in tm.items()))
         self.de = de
         if self.verbose >= 4:
             mf._log(4, "--------------- gradients ---------------")

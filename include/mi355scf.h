@@ -146,7 +146,8 @@ int mi_grad_1e(mi_ctx *ctx, const double *d_D, const double *d_W, double *d_grad
 /* d_grad[natm][3] += dE2/dR at fixed density: 2 sum (d mu nu|lam sig) [D D - hyb/4 (D D + D D)] over the
  * Schwarz-surviving quartets, derivative ERIs by the same Rys kernel on (l+1)/(l-1) auxiliary shells.
  * Replaces libcint int2e_ip1 + libcvhf nrs2/nrs4 J/K gradient contractions / gpu4pyscf rys gradient
- * kernels [MEM] (mf.nuc_grad_method().get_jk). */
+ * kernels [MEM] (mf.nuc_grad_method().get_jk).  On a sharded context the quartet batches are dealt
+ * round-robin to ranks: the result is a partial sum to be all-reduced by the caller. */
 int mi_grad_eri(mi_ctx *ctx, const double *d_D, double hyb, double *d_grad, void *stream);
 
 /* Real-solid-harmonic coefficient table used by the kernels: out[ncart(l)][2l+1] (host). */

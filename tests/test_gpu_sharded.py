@@ -31,7 +31,8 @@ def _worker(rank, world, port, method, q):
     mf.shard(rank, world)
     e = mf.kernel()
     st = mf.engine.stats()
-    q.put((rank, e, bool(mf.converged), st["n_tiles"], st["n_unique_eri"]))
+    g = mf.nuc_grad_method().kernel()
+    q.put((rank, e, bool(mf.converged), st["n_tiles"], st["n_unique_eri"], g.tolist()))
     import torch.distributed as dist
     dist.destroy_process_group()
 
@@ -49,6 +50,7 @@ def test_two_rank_sharded_scf_matches_single(method):
         mf.xc = method
     e1 = mf.kernel()
     st1 = mf.engine.stats()
+    g1 = mf.nuc_grad_method().kernel()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 90)
@@ -62,3 +64,6 @@ def test_two_rank_sharded_scf_matches_single(method):
     assert abs(res[0][1] - e1) < 1e-9 and abs(res[1][1] - e1) < 1e-9
     assert res[0][3] + res[1][3] == st1["n_tiles"] and min(res[0][3], res[1][3]) > 0
     assert res[0][4] + res[1][4] == st1["n_unique_eri"]
+    import numpy as np
+    for r in res:   # sharded analytic gradient (tasks + grid split over ranks, all-reduced) == unsharded
+        assert np.abs(np.array(r[5]) - g1).max() < 1e-8
