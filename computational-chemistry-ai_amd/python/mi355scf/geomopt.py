@@ -5,14 +5,71 @@ geomeTRIC (pinned 1.1 in the reference image, `.devcontainer/Dockerfile:120`) is
 independent quasi-Newton optimiser with geomeTRIC's DEFAULT convergence set [MEM]: |dE| < 1e-6 Ha,
 RMS/max gradient < 3e-4 / 4.5e-4 Ha/Bohr, RMS/max displacement < 1.2e-3 / 1.8e-3 Angstrom.  Step-for-step
 parity with geomeTRIC is impossible; only the converged geometry/energy within those thresholds is comparable.
-BFGS in Cartesian coordinates, trust-radius limited, Hessian guess 0.5 Ha/Bohr^2 on the diagonal.
-Returns a `Mole` at the optimised geometry, like the PySCF wrapper.
+BFGS in Cartesian coordinates, trust-radius limited; the initial Hessian is a valence-force-field model
+(stretches 0.5, bends 0.2, torsions 0.1 a.u. on the detected bond graph, B^T K B) so that floppy molecules
+converge in tens of steps.  Returns a `Mole` at the optimised geometry, like the PySCF wrapper.
 """
+import itertools
+
 import numpy as np
 
 from .mole import BOHR
 
 CONV = dict(energy=1e-6, grms=3e-4, gmax=4.5e-4, drms=1.2e-3, dmax=1.8e-3)
+_COV = {1: 0.31, 2: 0.28, 3: 1.28, 4: 0.96, 5: 0.84, 6: 0.76, 7: 0.71, 8: 0.66, 9: 0.57, 10: 0.58,
+        11: 1.66, 12: 1.41, 13: 1.21, 14: 1.11, 15: 1.07, 16: 1.05, 17: 1.02, 18: 1.06}
+
+
+def _bond(x, i, j):
+    return np.linalg.norm(x[i] - x[j])
+
+
+def _angle(x, i, j, k):
+    a, b = x[i] - x[j], x[k] - x[j]
+    return np.arccos(np.clip(a @ b / np.linalg.norm(a) / np.linalg.norm(b), -1.0, 1.0))
+
+
+def _dihedral(x, i, j, k, l):
+    b0, b1, b2 = x[i] - x[j], x[k] - x[j], x[l] - x[k]
+    b1n = b1 / np.linalg.norm(b1)
+    v, w = b0 - (b0 @ b1n) * b1n, b2 - (b2 @ b1n) * b1n
+    return np.arctan2(np.cross(b1n, v) @ w, v @ w)
+
+
+def model_hessian(mol, x):
+    """Cartesian model Hessian B^T K B from the bond graph (numerical Wilson B rows)."""
+    n = len(x)
+    z = mol.atom_charges()
+    rc = np.array([_COV.get(int(q), 1.2) for q in z]) / BOHR
+    nb = [[] for _ in range(n)]
+    bonds = []
+    for i in range(n):
+        for j in range(i):
+            if _bond(x, i, j) < 1.3 * (rc[i] + rc[j]):
+                bonds.append((i, j)); nb[i].append(j); nb[j].append(i)
+    ics = [(_bond, b, 0.5) for b in bonds]
+    for j in range(n):
+        for i, k in itertools.combinations(nb[j], 2):
+            ics.append((_angle, (i, j, k), 0.2))
+    for (j, k) in bonds:
+        for i in nb[j]:
+            for l in nb[k]:
+                if len({i, j, k, l}) == 4:
+                    ics.append((_dihedral, (i, j, k, l), 0.1))
+    H = np.eye(3 * n) * 0.02
+    h = 1e-4
+    for fn, idx, kf in ics:
+        row = np.zeros(3 * n)
+        for a in idx:
+            for c in range(3):
+                xp, xm = x.copy(), x.copy()
+                xp[a, c] += h; xm[a, c] -= h
+                d = fn(xp, *idx) - fn(xm, *idx)
+                if fn is _dihedral:
+                    d = (d + np.pi) % (2 * np.pi) - np.pi
+                row[3 * a + c] = d / (2 * h)
+        H += kf * np.outer(row, row)
+    return H
 
 
 def optimize(mf, maxsteps=100, callback=None, **kw):
@@ -20,7 +77,7 @@ def optimize(mf, maxsteps=100, callback=None, **kw):
     mol = mf.mol
     x = mol.atom_coords().ravel().copy()
     n = x.size
-    H = np.eye(n) * 0.5
+    H = model_hessian(mol, x.reshape(-1, 3))
     trust = 0.3
     e, g = gs(mol)
     g = g.ravel()

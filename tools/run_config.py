@@ -34,6 +34,13 @@ st = mf.engine.stats()
 ms = mf.engine.time_jk_kernel(mf._dm, reps=10)
 n = mol.nao
 alg = 8.0 * st["n_unique_eri"] + 24.0 * n * n
+opt = [a for a in sys.argv if a.startswith("--opt=")]
+if opt:
+    from pyscf.geomopt.geometric_solver import optimize
+    mf.verbose = 3; mol.verbose = 3
+    t1 = time.time()
+    mol_opt = optimize(mf, maxsteps=int(opt[0].split("=")[1]))
+    print(f"optimize wall {time.time() - t1:.1f} s")
 gt = None
 if do_grad:
     t1 = time.time(); g = mf.nuc_grad_method().kernel(); torch.cuda.synchronize(); gt = time.time() - t1
