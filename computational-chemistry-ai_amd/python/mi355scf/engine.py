@@ -67,6 +67,7 @@ def lib():
         L.mi_xc_aow.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
+        L.mi_sp2_iterate.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, ctypes.POINTER(vp), vp]
         L.mi_grad_1e.argtypes = [vp, vp, vp, vp, vp]
         L.mi_grad_eri.argtypes = [vp, vp, ctypes.c_double, vp, vp]
         L.mi_c2s_table.argtypes = [ctypes.c_int, dp]
@@ -243,6 +244,13 @@ class Engine:
 
     def sp2_update(self, X, X2, nocc, out):
         _check(lib().mi_sp2_update(self._h, X.data_ptr(), X2.data_ptr(), float(nocc), out.data_ptr(), self._stream()))
+
+    def sp2_iterate(self, X, X2, nit, nocc, work, tr):
+        """Fused SP2 passes (N <= 512); returns the offset (in doubles) inside `tr` of {tr X, tr X^2}."""
+        out = ctypes.c_void_p()
+        _check(lib().mi_sp2_iterate(self._h, X.data_ptr(), X2.data_ptr(), int(nit), float(nocc), 0, work.data_ptr(),
+                                    tr.data_ptr(), ctypes.byref(out), self._stream()))
+        return (out.value - tr.data_ptr()) // 8
 
     # --- row a10 -------------------------------------------------------------------------------
     def diis_errvec(self, sdf, out):

@@ -89,6 +89,8 @@ class SCF:
     #  'eigh' hipSOLVER generalised eigenproblem every cycle (what PySCF's `eig` does [MEM]).
     eig_method = "sp2"
     sp2_tol = 1e-11
+    sp2_fused = True   # small N: one fused HIP launch per SP2 step instead of rocBLAS DGEMM + update kernel
+    sp2_fused_max = 160  # measured: fused wins at N=114 (0.92 -> 0.80 ms/cycle), rocBLAS wins at N=264
 
     def __init__(self, mol):
         if not isinstance(mol, Mole):
@@ -204,6 +206,8 @@ class SCF:
         if nocc == 0 or nocc >= n:
             return None
         eng = self.engine
+        if n <= self.sp2_fused_max and self.sp2_fused:
+            return self._density_sp2_fused(fo, nocc)
         buf = getattr(self, "_sp2_buf", None)
         if buf is None or buf[0].numel() != 2 + n * n:
             buf = [torch.empty(2 + n * n, dtype=torch.float64, device=fo.device) for _ in range(2)]
@@ -230,6 +234,27 @@ class SCF:
                 self._sp2_iters = max(8, nit - 2) if attempt == 0 else nit + 2
                 return 2.0 * (Li.T @ X @ Li)
             nit += 8
+        return None
+
+    def _density_sp2_fused(self, fo, nocc):
+        """Same SP2 recursion, one fused HIP launch per step (`sp2_fused_kernel`, FP64 MFMA)."""
+        eng, Li = self.engine, self._Linv
+        n = fo.shape[0]
+        ws = getattr(self, "_sp2f", None)
+        if ws is None or ws["X"].shape[0] != n:
+            mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
+            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2))
+        nit = min(getattr(self, "_sp2_iters", 24), 72)
+        target = float(nocc)
+        for attempt in range(5):
+            eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
+            off = eng.sp2_iterate(ws["X"], ws["X2"], nit, target, ws["work"], ws["tr"])
+            tr = ws["tr"][off:off + 2].cpu()
+            err = float(tr[0] - tr[1])
+            if abs(err) < self.sp2_tol and abs(float(tr[0]) - target) < 1e-8:
+                self._sp2_iters = max(8, nit - 2) if attempt == 0 else nit
+                return 2.0 * (Li.T @ ws["X"] @ Li)
+            nit = min(nit + 8, 76)
         return None
 
     def make_rdm1(self, mo_coeff=None, mo_occ=None):

@@ -107,6 +107,12 @@ int mi_sp2_init(mi_ctx *ctx, const double *d_F, double *d_X, double *d_work, voi
 int mi_sp2_update(mi_ctx *ctx, double *d_X, const double *d_X2, double n_occ, double *d_out_with_traces,
                   void *stream);
 
+/* Fused SP2 for N <= 512: one launch per step (X*X on v_mfma_f64_16x16x4_f64 + branch + update + traces).
+ * d_X holds X0 (or a previous iterate), d_X2 receives X^2; d_work: 2*n*n doubles; d_tr: 2*(nit+2) doubles.
+ * Runs one squaring pass plus `nit` update+square passes; *d_tr_out points at {tr X, tr X^2} (device). */
+int mi_sp2_iterate(mi_ctx *ctx, double *d_X, double *d_X2, int nit, double n_occ, int have_x2,
+                   double *d_work, double *d_tr, double **d_tr_out, void *stream);
+
 /* ---- DFT -------------------------------------------------------------- */
 
 /* Becke fuzzy-cell weights for `ng` atom-centred grid points: d_coords[ng][3] (Bohr), d_atom_of[ng]
