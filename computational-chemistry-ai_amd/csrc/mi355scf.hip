@@ -1476,6 +1476,15 @@ __global__ __launch_bounds__(256) void diis_dots_kernel(const double *hist, cons
     if (threadIdx.x == 0) out[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+extern "C" int mi_diis_dots_dev(mi_ctx *c, const double *d_hist_e, const double *d_e, int n, double *d_out, void *stream)
+{
+    if (!c || n < 1 || n > 64 || !d_out) return fail("mi_diis_dots_dev: bad argument");
+    size_t nn = (size_t)c->nao * c->nao;
+    hipLaunchKernelGGL(diis_dots_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, d_hist_e, d_e, nn, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mi_diis_dots(mi_ctx *c, const double *d_hist_e, const double *d_e, int n, double *out, void *stream)
 {
     if (!c || n < 1 || n > 64) return fail("mi_diis_dots: bad argument");

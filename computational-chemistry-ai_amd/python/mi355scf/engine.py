@@ -59,6 +59,7 @@ def lib():
         L.mi_diis_errvec.argtypes = [vp, vp, vp, vp]
         L.mi_diis_combine.argtypes = [vp, vp, dp, ctypes.c_int, vp, vp]
         L.mi_diis_dots.argtypes = [vp, vp, vp, ctypes.c_int, dp, vp]
+        L.mi_diis_dots_dev.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp]
         i64 = ctypes.c_int64
         L.mi_grid_becke.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         L.mi_eval_ao.argtypes = [vp, vp, i64, ctypes.c_int, vp, vp]
@@ -259,6 +260,9 @@ class Engine:
     def diis_combine(self, hist, coef, out):
         c = np.ascontiguousarray(coef, dtype=np.float64)
         _check(lib().mi_diis_combine(self._h, hist.data_ptr(), _dp(c), len(c), out.data_ptr(), self._stream()))
+
+    def diis_dots_dev(self, hist_e, e, n, out):
+        _check(lib().mi_diis_dots_dev(self._h, hist_e.data_ptr(), e.data_ptr(), n, out.data_ptr(), self._stream()))
 
     def diis_dots(self, hist_e, e, n):
         out = np.zeros(n)

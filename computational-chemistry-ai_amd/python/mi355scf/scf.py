@@ -47,6 +47,38 @@ class DeviceDIIS:
         self.B = np.zeros((space, space))
         self._e = torch.empty(n, n, dtype=torch.float64, device=eng.device)
 
+    # --- split form used by the SCF step: `push` (device only, no sync) then `extrapolate` (host solve) ---
+    def push(self, f, e):
+        """Store (F_i, e_i); leaves the new Gram row <e_j, e_i> in `self.dots_dev[:m]` on the device."""
+        slot = self.count % self.space
+        self.F[slot].copy_(f)
+        self.E[slot].copy_(e)
+        self.count += 1
+        m = min(self.count, self.space)
+        if not hasattr(self, "dots_dev"):
+            self.dots_dev = torch.zeros(self.space, dtype=torch.float64, device=f.device)
+        self.eng.diis_dots_dev(self.E, self.E[slot], m, self.dots_dev)
+        self._pending = (slot, m)
+        return m
+
+    def extrapolate(self, dots):
+        slot, m = self._pending
+        dots = np.asarray(dots, dtype=np.float64)[:m]
+        self.B[slot, :m] = dots
+        self.B[:m, slot] = dots
+        A = np.zeros((m + 1, m + 1))
+        A[0, 1:] = A[1:, 0] = 1.0
+        A[1:, 1:] = self.B[:m, :m]
+        rhs = np.zeros(m + 1)
+        rhs[0] = 1.0
+        try:
+            c = np.linalg.solve(A, rhs)
+        except np.linalg.LinAlgError:
+            c = np.linalg.lstsq(A, rhs, rcond=None)[0]
+        out = torch.empty_like(self.F[0])
+        self.eng.diis_combine(self.F, c[1:], out)
+        return out
+
     def update(self, s, d, f):
         sdf = s @ d @ f
         self.eng.diis_errvec(sdf, self._e)
@@ -149,6 +181,7 @@ class SCF:
         S, T, V = eng.int1e()
         self._S, self._h1 = S, T + V
         L = torch.linalg.cholesky(S)
+        self._L = L
         self._Linv = torch.linalg.solve_triangular(L, torch.eye(eng.nao, dtype=torch.float64, device=eng.device), upper=False)
         if not eng.eri_ready:
             st = eng.prepare_eri(self.direct_scf_tol, self._rank, self._nranks)
@@ -197,11 +230,13 @@ class SCF:
         e, c = torch.linalg.eigh(Li @ f @ Li.T)
         return e, Li.T @ c
 
-    def _density_sp2(self, f, nocc):
-        """D = 2 P_occ(F) without diagonalisation.  Returns None if the purification does not converge
-        (e.g. vanishing HOMO-LUMO gap); the caller then falls back to `eigh`."""
+    def _density_sp2(self, f, nocc, orth=False):
+        """2 P_occ(F) without diagonalisation: D' in the orthonormal basis if `orth` (then `f` is F'), else
+        the AO density.  Returns None if the purification does not converge (e.g. vanishing HOMO-LUMO gap);
+        the caller then falls back to `eigh`."""
         Li = self._Linv
-        fo = Li @ f @ Li.T
+        self._sp2_orth = orth
+        fo = f if orth else Li @ f @ Li.T
         n = fo.shape[0]
         if nocc == 0 or nocc >= n:
             return None
@@ -232,7 +267,7 @@ class SCF:
             err = float(tr[0] - tr[1])          # = sum lambda (1 - lambda) >= 0
             if abs(err) < self.sp2_tol and abs(float(tr[0]) - target) < 1e-8:
                 self._sp2_iters = max(8, nit - 2) if attempt == 0 else nit + 2
-                return 2.0 * (Li.T @ X @ Li)
+                return 2.0 * X if self._sp2_orth else 2.0 * (Li.T @ X @ Li)
             nit += 8
         return None
 
@@ -253,7 +288,7 @@ class SCF:
             err = float(tr[0] - tr[1])
             if abs(err) < self.sp2_tol and abs(float(tr[0]) - target) < 1e-8:
                 self._sp2_iters = max(8, nit - 2) if attempt == 0 else nit
-                return 2.0 * (Li.T @ ws["X"] @ Li)
+                return 2.0 * ws["X"] if self._sp2_orth else 2.0 * (Li.T @ ws["X"] @ Li)
             nit = min(nit + 8, 76)
         return None
 
@@ -303,45 +338,60 @@ class SCF:
 
     # --- the SCF loop (row a12) -----------------------------------------------------------------
     def _start(self, dm0=None):
-        """Prepare integrals/ERIs and the iteration state (dm, vhf, e_tot, diis)."""
+        """Prepare integrals/ERIs and the iteration state.  The loop works in the Cholesky-orthogonalised
+        basis (F' = L^-1 F L^-T, D' = L^T D L); the DIIS error vector is PySCF's AO-basis FDS - SDF =
+        L (F'D' - D'F') L^T, so the extrapolation path is the reference one."""
         mol = self.mol
         self._setup_once()
         eng = self.engine
         if dm0 is None:
             dm0 = self.get_init_guess()
         dm = torch.as_tensor(np.asarray(dm0), dtype=torch.float64, device=eng.device).contiguous()
-        st = {"nocc": mol.nelectron // 2, "enuc": mol.energy_nuc(), "dm": dm, "cycle": 0}
-        st["vhf"], e2 = self._veff(dm)
-        st["e_tot"] = float(torch.sum(dm * self._h1) + e2) + st["enuc"]
-        st["diis"] = DeviceDIIS(eng, self.diis_space)
+        st = {"nocc": mol.nelectron // 2, "enuc": mol.energy_nuc(), "cycle": 0, "diis": DeviceDIIS(eng, self.diis_space)}
+        st["dmo"] = self._L.T @ dm @ self._L
+        self._after_density(st, dm, e_last=None, next_cycle=0)
         return st
 
+    def _after_density(self, st, dm, e_last, next_cycle):
+        """J/K(+XC) for `dm`, new Fock in the orthonormal basis, commutator error, energy, |g|; pushes
+        (F', e) into the DIIS history and fetches all scalars of the cycle with ONE device-to-host copy."""
+        Li, L, h1 = self._Linv, self._L, self._h1
+        vhf, e2 = self._veff(dm)
+        fo = Li @ (h1 + vhf) @ Li.T
+        m = fo @ st["dmo"]
+        eo = m - m.T                                   # [F', D']
+        e_ao = L @ eo @ L.T                            # = F D S - S D F  (PySCF's CDIIS error vector [MEM])
+        # PySCF feeds CDIIS only from cycle `diis_start_cycle` on [MEM]: the initial-guess Fock is not stored
+        nd = st["diis"].push(fo, e_ao) if next_cycle >= self.diis_start_cycle else 0
+        n = fo.shape[0]
+        nvo = max((n - st["nocc"]) * st["nocc"], 1)
+        scal = torch.stack([torch.sum(dm * h1) + e2, torch.linalg.norm(eo)])
+        vals = (torch.cat([st["diis"].dots_dev[:nd], scal]) if nd else scal).cpu().numpy()   # the cycle's only host sync
+        e_tot = float(vals[nd]) + st["enuc"]
+        # |g| = |2 F_vo| = |[F',D']|_F / sqrt(2), normalised by sqrt(n_vo) like PySCF's get_grad norm [MEM]
+        gnorm = float(vals[nd + 1]) / np.sqrt(2.0) / np.sqrt(nvo)
+        st.update(dm=dm, vhf=vhf, fo=fo, dots=vals[:nd], e_tot=e_tot, gnorm=gnorm,
+                  de=(e_tot - e_last) if e_last is not None else 0.0)
+
     def _step(self, st, use_diis=True, want_mo=False):
-        """One SCF cycle: Fock (+CDIIS) -> eig -> density -> J/K -> energy, orbital gradient.  This is
-        the unit bench.py times ("SCF iteration")."""
-        S, h1, nocc = self._S, self._h1, st["nocc"]
-        f = h1 + st["vhf"]
+        """One SCF cycle: CDIIS extrapolation -> occupied projector (SP2 or eigh) -> density -> J/K ->
+        energy, orbital gradient.  This is the unit bench.py times ("SCF iteration")."""
+        nocc, Li = st["nocc"], self._Linv
         if use_diis and st["cycle"] >= self.diis_start_cycle:
-            f = st["diis"].update(S, st["dm"], f)
-        dm = self._density_sp2(f, nocc) if (self.eig_method == "sp2" and not want_mo) else None
-        if dm is None:
-            mo_e, mo_c = self._eig(f)
-            co = mo_c[:, :nocc]
-            dm = 2.0 * co @ co.T
-            st.update(mo_e=mo_e, mo_c=mo_c)
+            fo = st["diis"].extrapolate(st["dots"])
+        else:
+            fo = st["fo"]
+        dmo = self._density_sp2(fo, nocc, orth=True) if (self.eig_method == "sp2" and not want_mo) else None
+        if dmo is None:
+            e, c = torch.linalg.eigh(fo)
+            co = c[:, :nocc]
+            dmo = 2.0 * co @ co.T
+            st.update(mo_e=e, mo_c=Li.T @ c)
         else:
             st.pop("mo_e", None)
-        vhf, e2 = self._veff(dm)
-        e_last = st["e_tot"]
-        fock = h1 + vhf
-        fds = fock @ dm @ S
-        comm = self._Linv @ (fds - fds.T) @ self._Linv.T   # [F', D'] in the orthonormal basis
-        nvo = max((S.shape[0] - nocc) * nocc, 1)
-        # |g| = |2 F_vo| = |[F',D']|_F / sqrt(2)  (identical to PySCF's get_grad norm [MEM])
-        vals = torch.stack([torch.sum(dm * h1) + e2, torch.linalg.norm(comm)]).cpu()   # one host sync
-        e_tot = float(vals[0]) + st["enuc"]
-        gnorm = float(vals[1]) / np.sqrt(2.0) / np.sqrt(nvo)
-        st.update(dm=dm, vhf=vhf, e_tot=e_tot, de=e_tot - e_last, gnorm=gnorm)
+        st["dmo"] = dmo
+        dm = Li.T @ dmo @ Li
+        self._after_density(st, dm, e_last=st["e_tot"], next_cycle=st["cycle"] + 1)
         st["cycle"] += 1
         return st
 
@@ -366,7 +416,8 @@ class SCF:
             self._step(st, use_diis=False, want_mo=True)
             self._log(4, f"Extra cycle  E= {st['e_tot']:.15g}  delta_E= {st['de']:.3g}")
         if "mo_e" not in st:  # not converged (or max_cycle == 0): orbitals of the last Fock matrix
-            st["mo_e"], st["mo_c"] = self._eig(self._h1 + st["vhf"])
+            e_, c_ = torch.linalg.eigh(st["fo"])
+            st["mo_e"], st["mo_c"] = e_, self._Linv.T @ c_
         self._dm, self._vhf = st["dm"], st["vhf"]
         self.e_tot = float(st["e_tot"])
         self.mo_energy = st["mo_e"].cpu().numpy()

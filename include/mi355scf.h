@@ -95,6 +95,10 @@ int mi_diis_combine(mi_ctx *ctx, const double *d_hist, const double *coef, int n
 /* Gram matrix row: out[i] = <d_hist_e[i], d_e> for i < n (host output, synchronises `stream`). */
 int mi_diis_dots(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int n, double *out,
                  void *stream);
+/* Same, result left on the device (d_out[n]), no synchronisation: lets the SCF step fetch the Gram row,
+ * the energy and the gradient norm with ONE device-to-host copy. */
+int mi_diis_dots_dev(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int n, double *d_out,
+                     void *stream);
 
 
 /* ---- density from the Fock matrix without diagonalisation (row a11) ----------------------------- */
