@@ -2492,26 +2492,34 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *Xp, const 
     double *red = Pb + 16 * (kpad + 4);     // [4][256]
     const int ldp = kpad + 4;               // +4 doubles: breaks the power-of-two LDS row stride
     const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
-    bool sq = false;
-    if (!first) {
-        double tx = trp[0], tx2 = trp[1];
-        sq = fabs(tx2 - target) < fabs(2.0 * tx - tx2 - target);
-    }
-    for (int idx = threadIdx.x; idx < 16 * kpad; idx += 256) {
-        int r = idx / kpad, k = idx - r * kpad;
-        double va = 0.0, vb = 0.0;
-        if (k < n) {
-            if (i0 + r < n) {
-                size_t o = (size_t)(i0 + r) * n + k;
-                va = first ? Xp[o] : (sq ? X2p[o] : 2.0 * Xp[o] - X2p[o]);
-            }
-            if (j0 + r < n) {
-                size_t o = (size_t)(j0 + r) * n + k;
-                vb = first ? Xp[o] : (sq ? X2p[o] : 2.0 * Xp[o] - X2p[o]);
+    // the branch decision needs the traces of the previous launch (memory-side atomics: a full-latency
+    // read).  Issue it together with the panel loads and select afterwards, so the two latencies overlap.
+    const double tx = first ? 0.0 : trp[0], tx2 = first ? 0.0 : trp[1];
+    constexpr int PER = 16; // panel elements per thread per batch
+    for (int base = 0; base < 16 * kpad; base += 256 * PER) {
+        double xa[PER], ya[PER], xb[PER], yb[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            int idx = base + u * 256 + threadIdx.x;
+            int r = idx / kpad, k = idx - r * kpad;
+            bool in = idx < 16 * kpad && k < n;
+            bool ina = in && (i0 + r < n), inb = in && (j0 + r < n);
+            size_t oa = (size_t)(i0 + r) * n + k, ob = (size_t)(j0 + r) * n + k;
+            xa[u] = ina ? Xp[oa] : 0.0;
+            xb[u] = inb ? Xp[ob] : 0.0;
+            ya[u] = (ina && !first) ? X2p[oa] : 0.0;
+            yb[u] = (inb && !first) ? X2p[ob] : 0.0;
+        }
+        const bool sq = !first && fabs(tx2 - target) < fabs(2.0 * tx - tx2 - target);
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            int idx = base + u * 256 + threadIdx.x;
+            if (idx < 16 * kpad) {
+                int r = idx / kpad, k = idx - r * kpad;
+                Pa[r * ldp + k] = first ? xa[u] : (sq ? ya[u] : 2.0 * xa[u] - ya[u]);
+                Pb[r * ldp + k] = first ? xb[u] : (sq ? yb[u] : 2.0 * xb[u] - yb[u]);
             }
         }
-        Pa[r * ldp + k] = va;
-        Pb[r * ldp + k] = vb;
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
