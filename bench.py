@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--basis", default="cc-pVDZ")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eig", default="sp2", choices=["sp2", "eigh"], help="projector method inside the SCF step")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; 'gloo' only for rehearsing N>1 ranks on a 1-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -67,10 +69,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local)
+    ndev = torch.cuda.device_count()
+    dev = local if args.backend == "nccl" else local % max(ndev, 1)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     mol = Mole(atom=BENZENE, basis=args.basis, verbose=0).build()
@@ -98,7 +105,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
