@@ -564,6 +564,8 @@ struct EriArgs {
     RysDev rys;
     int diag;                // 1: Schwarz mode, ket == bra and task b -> (b,b)
     int swap;                // 1: the task's (bra index, ket index) address (ket[], bra[]) instead
+    const int32_t *own_table; // non-null on a sharded context: skip quartets none of whose tiles live on this rank
+    int ni, nj, nk, nl;       // spherical shell sizes (for the ownership test)
 };
 
 __device__ inline void find_task(const int64_t *prefix, int nbra, int64_t t, int &ib, int &ik)
@@ -577,6 +579,26 @@ __device__ inline void find_task(const int64_t *prefix, int nbra, int64_t t, int
     ik = (int)(t - prefix[lo]);
 }
 
+// Does any AO quadruple of the shell quartet land in a tile that is resident on this rank?  (<= 16 block
+// combinations; every symmetry image of a quadruple maps to the same canonical tile.)
+__device__ inline bool quartet_has_resident_tile(const int32_t *table, int ao_i, int ni, int ao_j, int nj, int ao_k, int nk,
+                                                 int ao_l, int nl, int lane)
+{
+    bool hit = false;
+    if (lane < 16) {
+        int I = (lane & 1) ? (ao_i + ni - 1) >> 3 : ao_i >> 3;
+        int J = (lane & 2) ? (ao_j + nj - 1) >> 3 : ao_j >> 3;
+        int K = (lane & 4) ? (ao_k + nk - 1) >> 3 : ao_k >> 3;
+        int L = (lane & 8) ? (ao_l + nl - 1) >> 3 : ao_l >> 3;
+        int hi = max(I, J), lo = min(I, J), bij = hi * (hi + 1) / 2 + lo;
+        hi = max(K, L); lo = min(K, L);
+        int bkl = hi * (hi + 1) / 2 + lo;
+        int bmax = max(bij, bkl), bmin = min(bij, bkl);
+        hit = table[(size_t)bmax * (bmax + 1) / 2 + bmin] >= 0;
+    }
+    return __any(hit);
+}
+
 template <int MAXC>
 __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
 {
@@ -588,6 +610,7 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
     else find_task(A.prefix, A.nbra, task, ib, ik);
     if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
+    if (A.own_table && !quartet_has_resident_tile(A.own_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane)) return;
     const int n = A.nroots, tsz = A.tsz, M1 = A.mmax + 1;
     const int ncd = cd.nprim, nPQ = ab.nprim * ncd;
     const int PB = A.PB;
@@ -691,6 +714,7 @@ struct XfArgs {
     const int64_t *tile_off;
     double *tiles;
     int nao;
+    int check_owner, ni, nj, nk, nl;
 };
 
 __device__ inline void put_tile(const XfArgs &A, int i, int j, int k, int l, double v)
@@ -717,6 +741,7 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
     int ib, ik;
     find_task(A.prefix, A.nbra, A.t0 + blockIdx.x, ib, ik);
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
+    if (A.check_owner && !quartet_has_resident_tile(A.tile_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane)) return;
     const double *E0g = A.work + (size_t)blockIdx.x * A.ncomp;
     double *E0 = lds;                 // [ne][nf]
     double *X = lds + A.ne * A.nf;    // [nsab][nf]
@@ -872,6 +897,14 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     auto t_start = std::chrono::steady_clock::now();
+    auto t_phase = t_start;
+    auto lap = [&](const char *what) {
+        if (!getenv("MI355_DEBUG")) return;
+        hipStreamSynchronize(st);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mi355] eri_prepare %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
     free_eri(c);
     const int nbas = c->nbas;
     std::vector<std::vector<double>> c2s(LMAX + 1);
@@ -930,6 +963,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     if (upload(&c->d_prim, prim)) return -1;
     if (upload(&c->d_M, Mbuf)) return -1;
 
+    lap("pairs + M matrices");
     // workspace for cartesian intermediates
     const size_t WORK_DOUBLES = (size_t)32 << 20; // 256 MiB
     double *d_work = nullptr;
@@ -968,6 +1002,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     for (int ci = 0; ci < NPC; ci++)
         for (double v : c->pc[ci].q) qmax = std::max(qmax, v);
 
+    lap("schwarz");
     // ---- 3. sort pairs by q (descending), drop negligible ones; block-pair Schwarz bounds
     const int nblk = c->nblk;
     const int nbp = nblk * (nblk + 1) / 2;
@@ -997,6 +1032,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         if (upload(&P.d_recs, P.recs)) return -1;
     }
 
+    lap("sort pairs");
     // ---- 4. tiles and runs.  Run = tiles sharing (J,K,L), ordered by I; long runs are split.
     const int RUNMAX = 1 << 30; // runs are kept whole here (sharding unit); J/K work items are cut below
     std::vector<int> bpI(nbp), bpJ(nbp);
@@ -1126,6 +1162,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     HIPCHK(hipMalloc(&c->d_tiles, sizeof(double) * std::max<int64_t>(off, 1)));
     HIPCHK(hipMemsetAsync(c->d_tiles, 0, sizeof(double) * std::max<int64_t>(off, 1), st));
 
+    lap("tiles/runs/segments + alloc");
     // ---- 5. evaluate every Schwarz-surviving canonical shell quartet, class by class
     int64_t nquart = 0;
     int64_t *d_prefix = nullptr;
@@ -1161,11 +1198,14 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             HIPCHK(hipStreamSynchronize(st)); // host vectors go out of scope below
             E.bra = B.d_recs; E.ket = Kc.d_recs; E.prim = c->d_prim; E.prefix = d_prefix; E.nbra = (int)B.recs.size();
             E.comp = d_comp; E.work = d_work; E.rys = c->rys; E.diag = 0;
+            E.ni = 2 * B.la + 1; E.nj = 2 * B.lb + 1; E.nk = 2 * Kc.la + 1; E.nl = 2 * Kc.lb + 1;
+            E.own_table = nranks > 1 ? c->d_tile_table : nullptr;
             XfArgs X{};
             X.bra = B.d_recs; X.ket = Kc.d_recs; X.Mbuf = c->d_M; X.prefix = d_prefix; X.nbra = E.nbra;
             X.ne = B.ne; X.nf = Kc.ne; X.nsab = B.nsab; X.nscd = Kc.nsab; X.nsb = 2 * B.lb + 1; X.nsd = 2 * Kc.lb + 1;
             X.work = d_work; X.ncomp = E.ncomp; X.tile_table = c->d_tile_table; X.tile_off = c->d_tile_off;
             X.tiles = c->d_tiles; X.nao = c->nao;
+            X.check_owner = nranks > 1; X.ni = E.ni; X.nj = E.nj; X.nk = E.nk; X.nl = E.nl;
             int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
             size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
             for (int64_t t0 = 0; t0 < ntask; t0 += per) {
@@ -1177,6 +1217,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             }
         }
     HIPCHK(hipStreamSynchronize(st));
+    lap("quartet evaluation");
     if (d_prefix) hipFree(d_prefix);
     hipFree(d_work);
     hipFree(d_comp);

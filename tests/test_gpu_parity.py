@@ -78,3 +78,28 @@ def test_jk_linearity_and_symmetry_benzene_sized():
     d1, d2 = torch.as_tensor(D1, device=J1.device), torch.as_tensor(D2, device=J1.device)
     assert abs(float((d1 * J2).sum() - (d2 * J1).sum())) < 1e-8
     assert abs(float((d1 * K2).sum() - (d2 * K1).sum())) < 1e-8
+
+
+def test_against_committed_golden_vectors():
+    """HIP path vs tests/golden/h2co_631gd_vectors.npz (made by tests/golden/make_golden_vectors.py)."""
+    import os
+    import torch
+    from mi355scf.engine import Engine
+    from mi355scf.dft import RKS
+    from mi355scf.fixtures import H2CO
+    from mi355scf.mole import Mole
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "h2co_631gd_vectors.npz"))
+    mol = Mole(atom=H2CO, basis="6-31g(d)", verbose=0).build()
+    eng = Engine(mol)
+    S, T, V, dip = (x.cpu().numpy() for x in eng.int1e(with_dipole=True))
+    assert np.abs(S - g["S"]).max() < 1e-12 and np.abs(T - g["T"]).max() < 1e-11
+    assert np.abs(V - g["V"]).max() < 1e-10 and np.abs(dip - g["dip"]).max() < 1e-11
+    J, K = eng.get_jk(g["D"])
+    assert np.abs(J.cpu().numpy() - g["J"]).max() < 1e-10 and np.abs(K.cpu().numpy() - g["K"]).max() < 1e-10
+    mf = RKS(mol, xc="B3LYP")
+    mf.grids.level = 1
+    mf._setup_once()
+    assert mf.grids.size == int(g["ngrid"]) and abs(float(mf.grids.weights.sum()) - float(g["wsum"])) < 1e-8
+    n, exc, vxc, hyb = mf.nr_rks(torch.as_tensor(g["Docc"], device=eng.device))
+    assert abs(float(n) - float(g["nelec"])) < 1e-9 and abs(float(exc) - float(g["exc"])) < 1e-9
+    assert np.abs(vxc.cpu().numpy() - g["vxc"]).max() < 1e-9 and hyb == float(g["hyb"])

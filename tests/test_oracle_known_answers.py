@@ -126,3 +126,15 @@ def test_oracle_dft_grid_and_functionals():
     cf = 0.3 * (3 * np.pi ** 2) ** (2 / 3)
     compact = -a * rho / Dn - a * b * om * (cf * rho ** (14 / 3) - rho ** 2 * sig * (1 / 24 + 7 * dl / 72))
     assert np.abs(compact - odft._lyp(rho / 2, rho / 2, sig / 4, sig / 4, sig / 4)).max() < 1e-15
+
+
+def test_oracle_reproduces_committed_golden_vectors():
+    from oracle import oracle as orc
+    from mi355scf import fixtures
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "h2co_631gd_vectors.npz"))
+    mol = _mol(fixtures.H2CO, "6-31g(d)")
+    o = orc.Oracle(mol)
+    S, T, V, dip = o.int1e()
+    assert np.abs(S - g["S"]).max() < 1e-13 and np.abs(V - g["V"]).max() < 1e-12
+    J, K = o.jk(g["D"], tol=0.0)
+    assert np.abs(J - g["J"]).max() < 1e-11 and np.abs(K - g["K"]).max() < 1e-11
