@@ -141,6 +141,7 @@ class SCF:
         self._eng = None
         self._dm = None
         self._rank, self._nranks, self._pg = 0, 1, None
+        self._stream_groups = 1   # >1: direct mode (ERI tile groups recomputed each Fock build)
         self.timing = {}
 
     # --- backend selection (row a14) ------------------------------------------------------------
@@ -183,11 +184,20 @@ class SCF:
         L = torch.linalg.cholesky(S)
         self._L = L
         self._Linv = torch.linalg.solve_triangular(L, torch.eye(eng.nao, dtype=torch.float64, device=eng.device), upper=False)
-        if not eng.eri_ready:
-            st = eng.prepare_eri(self.direct_scf_tol, self._rank, self._nranks)
-            self.timing["eri_seconds"] = st["seconds_eri"]
-            self._log(4, f"resident ERI store: {st['n_tiles']} tiles, {st['stored_bytes'] / 1e6:.1f} MB, "
-                         f"{st['n_quartets']} shell quartets in {st['seconds_eri']:.3f} s")
+        if not eng.eri_ready and self._stream_groups <= 1:
+            try:
+                st = eng.prepare_eri(self.direct_scf_tol, self._rank, self._nranks)
+                self.timing["eri_seconds"] = st["seconds_eri"]
+                self._log(4, f"resident ERI store: {st['n_tiles']} tiles, {st['stored_bytes'] / 1e6:.1f} MB, "
+                             f"{st['n_quartets']} shell quartets in {st['seconds_eri']:.3f} s")
+            except _engine.EngineError as e:
+                if "resident ERI store needs" not in str(e):
+                    raise
+                import re
+                need, free = (float(x) for x in re.findall(r"([0-9.]+) GB", str(e))[:2])
+                self._stream_groups = int(np.ceil(need / max(0.8 * free, 1.0)))
+                self._log(3, f"ERI tensor shard ({need:.0f} GB) exceeds free HBM ({free:.0f} GB): direct mode, "
+                             f"{self._stream_groups} tile groups are re-evaluated and digested every Fock build")
         self.timing["setup_seconds"] = time.time() - t0
 
     def get_ovlp(self, mol=None):
@@ -200,8 +210,24 @@ class SCF:
     def energy_nuc(self):
         return self.mol.energy_nuc()
 
+    def _jk_streamed(self, dm, with_j, with_k):
+        """Direct (recompute) mode: the rank's tile runs are cut into `_stream_groups` groups; each group is
+        evaluated by the Rys kernels, digested and discarded (same kernels as the resident mode)."""
+        eng = self.engine
+        ng = self._stream_groups
+        J = K = None
+        for v in range(ng):
+            eng.prepare_eri(self.direct_scf_tol, self._rank * ng + v, self._nranks * ng)
+            j, k = eng.get_jk(dm, with_j, with_k)
+            J = j if J is None else (J + j if with_j else None)
+            K = k if K is None else (K + k if with_k else None)
+        return J, K   # pair records / Schwarz data of the last group stay valid (used by the gradient)
+
     def _jk(self, dm, with_j=True, with_k=True):
-        J, K = self.engine.get_jk(dm, with_j, with_k)
+        if self._stream_groups > 1:
+            J, K = self._jk_streamed(dm, with_j, with_k)
+        else:
+            J, K = self.engine.get_jk(dm, with_j, with_k)
         if self._nranks > 1:
             from . import parallel
             parallel.all_reduce_fused([x for x in (J, K) if x is not None], self._pg)

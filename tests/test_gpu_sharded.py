@@ -67,3 +67,18 @@ def test_two_rank_sharded_scf_matches_single(method):
     import numpy as np
     for r in res:   # sharded analytic gradient (tasks + grid split over ranks, all-reduced) == unsharded
         assert np.abs(np.array(r[5]) - g1).max() < 1e-8
+
+
+def test_direct_mode_streamed_tile_groups_match_resident():
+    """Direct (recompute) J/K: tile groups evaluated, digested and discarded each build == resident mode."""
+    from pyscf import gto, scf
+    mol = gto.Mole()
+    mol.atom = MOLECULES["h2co"]
+    mol.basis = "6-31G(d)"
+    mol.verbose = 0
+    mol.build()
+    e1 = scf.RHF(mol).kernel()
+    mf = scf.RHF(mol)
+    mf._stream_groups = 3
+    e3 = mf.kernel()
+    assert mf.converged and abs(e1 - e3) < 1e-9
