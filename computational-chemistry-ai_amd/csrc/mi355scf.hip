@@ -2634,3 +2634,64 @@ extern "C" int mi_sp2_iterate(mi_ctx *c, double *d_X, double *d_X2, int nit, dou
     *d_tr_out = d_tr + 2 * slot;
     return 0;
 }
+
+// =================================================================================================
+// Fused elementwise pieces of the SCF cycle (fewer launches per cycle)
+// =================================================================================================
+// F = h + J - (kscale) K (+ Vxc), and scal[0] += sum D*(h + 0.5*(J - kscale K))  [one-electron + Coulomb/exchange energy]
+__global__ __launch_bounds__(256) void fock_energy_kernel(const double *h, const double *J, const double *K, const double *Vxc,
+                                                          const double *D, double kscale, size_t nn, double *F, double *scal)
+{
+    __shared__ double sh[4];
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double e = 0.0;
+    if (idx < nn) {
+        double v2 = J[idx] - (K ? kscale * K[idx] : 0.0);
+        double f = h[idx] + v2 + (Vxc ? Vxc[idx] : 0.0);
+        F[idx] = f;
+        e = D[idx] * (h[idx] + 0.5 * v2);
+    }
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&scal[0], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+extern "C" int mi_fock_energy(mi_ctx *c, const double *d_h, const double *d_J, const double *d_K, const double *d_Vxc,
+                              const double *d_D, double kscale, double *d_F, double *d_scal, void *stream)
+{
+    if (!c || !d_h || !d_J || !d_D || !d_F || !d_scal) return fail("mi_fock_energy: null argument");
+    size_t nn = (size_t)c->nao * c->nao;
+    hipLaunchKernelGGL(fock_energy_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_h, d_J, d_K, d_Vxc,
+                       d_D, kscale, nn, d_F, d_scal);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// E = M - M^T and scal[0] += sum E^2
+__global__ __launch_bounds__(256) void commutator_norm_kernel(const double *M, int n, double *E, double *scal)
+{
+    __shared__ double sh[4];
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double s = 0.0;
+    if (idx < (size_t)n * n) {
+        int r = (int)(idx / n), cidx = (int)(idx - (size_t)r * n);
+        double v = M[idx] - M[(size_t)cidx * n + r];
+        E[idx] = v;
+        s = v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&scal[0], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+extern "C" int mi_commutator_norm(mi_ctx *c, const double *d_M, double *d_E, double *d_scal, void *stream)
+{
+    if (!c || !d_M || !d_E || !d_scal) return fail("mi_commutator_norm: null argument");
+    int n = c->nao;
+    hipLaunchKernelGGL(commutator_norm_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_M, n, d_E,
+                       d_scal);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

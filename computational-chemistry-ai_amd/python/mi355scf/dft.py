@@ -97,6 +97,27 @@ class RKS(RHF):
         from . import parallel
         return parallel.split_range(ng, self._rank, self._nranks)
 
+    def _fock_energy(self, dm, scal):
+        nelec, exc, vxc, hyb = self._xc_reduced(dm)
+        self._nelec_grid = nelec
+        if abs(hyb) > 1e-12:
+            J, K = self._jk(dm)
+        else:
+            J, K = self._jk(dm, with_k=False)[0], None
+        F = torch.empty_like(J)
+        self.engine.fock_energy(self._h1, J, K, vxc, dm, 0.5 * hyb, F, scal)
+        scal += exc
+        return F
+
+    def _xc_reduced(self, dm):
+        nelec, exc, vxc, hyb = self.nr_rks(dm)
+        if self._nranks > 1:
+            from . import parallel
+            nelec, exc = nelec.reshape(1), exc.reshape(1)
+            parallel.all_reduce_fused([vxc, nelec, exc], self._pg)
+            nelec, exc = nelec[0], exc[0]
+        return nelec, exc, vxc, hyb
+
     def _veff(self, dm):
         nelec, exc, vxc, hyb = self.nr_rks(dm)
         if self._nranks > 1:

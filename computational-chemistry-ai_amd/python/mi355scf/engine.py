@@ -71,6 +71,8 @@ def lib():
         L.mi_sp2_iterate.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, ctypes.POINTER(vp), vp]
         L.mi_grad_1e.argtypes = [vp, vp, vp, vp, vp]
         L.mi_grad_eri.argtypes = [vp, vp, ctypes.c_double, vp, vp]
+        L.mi_fock_energy.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp]
+        L.mi_commutator_norm.argtypes = [vp, vp, vp, vp, vp]
         L.mi_c2s_table.argtypes = [ctypes.c_int, dp]
         L.mi_rys_roots_host.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp]
         _lib = L
@@ -252,6 +254,14 @@ class Engine:
         _check(lib().mi_sp2_iterate(self._h, X.data_ptr(), X2.data_ptr(), int(nit), float(nocc), 0, work.data_ptr(),
                                     tr.data_ptr(), ctypes.byref(out), self._stream()))
         return (out.value - tr.data_ptr()) // 8
+
+    def fock_energy(self, h, J, K, Vxc, D, kscale, F, scal):
+        _check(lib().mi_fock_energy(self._h, h.data_ptr(), J.data_ptr(), K.data_ptr() if K is not None else None,
+                                    Vxc.data_ptr() if Vxc is not None else None, D.data_ptr(), float(kscale), F.data_ptr(),
+                                    scal.data_ptr(), self._stream()))
+
+    def commutator_norm(self, M, E, scal):
+        _check(lib().mi_commutator_norm(self._h, M.data_ptr(), E.data_ptr(), scal.data_ptr(), self._stream()))
 
     # --- row a10 -------------------------------------------------------------------------------
     def diis_errvec(self, sdf, out):

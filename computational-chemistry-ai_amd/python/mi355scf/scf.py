@@ -245,6 +245,13 @@ class SCF:
         vhf = J - 0.5 * K
         return vhf, 0.5 * torch.sum(dm * vhf)
 
+    def _fock_energy(self, dm, scal):
+        """F = h + veff(D) on device and scal[0] += E_elec(D) (fused kernel).  Overridden by RKS."""
+        J, K = self._jk(dm)
+        F = torch.empty_like(J)
+        self.engine.fock_energy(self._h1, J, K, None, dm, 0.5, F, scal)
+        return F
+
     def get_veff(self, mol=None, dm=None, **kw):
         if dm is None:
             dm = self.make_rdm1()
@@ -382,21 +389,23 @@ class SCF:
         """J/K(+XC) for `dm`, new Fock in the orthonormal basis, commutator error, energy, |g|; pushes
         (F', e) into the DIIS history and fetches all scalars of the cycle with ONE device-to-host copy."""
         Li, L, h1 = self._Linv, self._L, self._h1
-        vhf, e2 = self._veff(dm)
-        fo = Li @ (h1 + vhf) @ Li.T
+        dm = dm.contiguous()
+        scal = torch.zeros(2, dtype=torch.float64, device=dm.device)   # [E_elec, |[F',D']|^2]
+        fock = self._fock_energy(dm, scal[0:1])
+        fo = Li @ fock @ Li.T
         m = fo @ st["dmo"]
-        eo = m - m.T                                   # [F', D']
+        eo = torch.empty_like(m)
+        self.engine.commutator_norm(m, eo, scal[1:2])  # eo = [F', D'] and its squared norm
         e_ao = L @ eo @ L.T                            # = F D S - S D F  (PySCF's CDIIS error vector [MEM])
         # PySCF feeds CDIIS only from cycle `diis_start_cycle` on [MEM]: the initial-guess Fock is not stored
         nd = st["diis"].push(fo, e_ao) if next_cycle >= self.diis_start_cycle else 0
         n = fo.shape[0]
         nvo = max((n - st["nocc"]) * st["nocc"], 1)
-        scal = torch.stack([torch.sum(dm * h1) + e2, torch.linalg.norm(eo)])
         vals = (torch.cat([st["diis"].dots_dev[:nd], scal]) if nd else scal).cpu().numpy()   # the cycle's only host sync
         e_tot = float(vals[nd]) + st["enuc"]
         # |g| = |2 F_vo| = |[F',D']|_F / sqrt(2), normalised by sqrt(n_vo) like PySCF's get_grad norm [MEM]
-        gnorm = float(vals[nd + 1]) / np.sqrt(2.0) / np.sqrt(nvo)
-        st.update(dm=dm, vhf=vhf, fo=fo, dots=vals[:nd], e_tot=e_tot, gnorm=gnorm,
+        gnorm = float(np.sqrt(max(vals[nd + 1], 0.0))) / np.sqrt(2.0) / np.sqrt(nvo)
+        st.update(dm=dm, vhf=fock - h1, fo=fo, dots=vals[:nd], e_tot=e_tot, gnorm=gnorm,
                   de=(e_tot - e_last) if e_last is not None else 0.0)
 
     def _step(self, st, use_diis=True, want_mo=False):

@@ -117,6 +117,13 @@ int mi_sp2_update(mi_ctx *ctx, double *d_X, const double *d_X2, double n_occ, do
 int mi_sp2_iterate(mi_ctx *ctx, double *d_X, double *d_X2, int nit, double n_occ, int have_x2,
                    double *d_work, double *d_tr, double **d_tr_out, void *stream);
 
+/* Fused elementwise pieces of one SCF cycle (rows a11/a12: get_fock + energy_elec, orbital-gradient norm):
+ * mi_fock_energy: F = h + J - kscale*K (+Vxc); *d_scal += sum D*(h + (J - kscale*K)/2).  d_K, d_Vxc may be NULL.
+ * mi_commutator_norm: E = M - M^T; *d_scal += |E|_F^2.   d_scal must be zeroed by the caller. */
+int mi_fock_energy(mi_ctx *ctx, const double *d_h, const double *d_J, const double *d_K, const double *d_Vxc,
+                   const double *d_D, double kscale, double *d_F, double *d_scal, void *stream);
+int mi_commutator_norm(mi_ctx *ctx, const double *d_M, double *d_E, double *d_scal, void *stream);
+
 /* ---- DFT -------------------------------------------------------------- */
 
 /* Becke fuzzy-cell weights for `ng` atom-centred grid points: d_coords[ng][3] (Bohr), d_atom_of[ng]
