@@ -1,0 +1,98 @@
+"""CPU tests of the host-side logic of the product (no GPU, no engine calls): Mole parsing/packing, basis
+normalisation, XC name parsing, grid tables, SMILES fixtures, optimiser model Hessian, loud failure without a GPU."""
+import numpy as np
+import pytest
+
+from conftest import MOLECULES
+
+
+def test_mole_parsing_units_and_counts():
+    from mi355scf.mole import Mole, BOHR
+    m1 = Mole(atom="O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587", basis="6-31G(d)").build()
+    m2 = Mole(atom="""
+        O  0.0  0.0   0.0
+        H  0.0 -0.757 0.587
+        H  0.0  0.757 0.587
+    """, basis="6-31g*", unit="Angstrom").build()
+    assert m1.nao == m2.nao == 2 + 2 + 14 and m1.nelectron == 10 and m1.natm == 3
+    assert np.allclose(m1.atom_coords(), m2.atom_coords()) and np.allclose(m1.atom_coords()[1] * BOHR, [0, -0.757, 0.587])
+    m3 = m1.set_geom_(m1.atom_coords() * 1.01, unit="Bohr", inplace=False)
+    assert np.allclose(m3.atom_coords(), m1.atom_coords() * 1.01) and m3 is not m1
+    with pytest.raises(RuntimeError):
+        Mole(atom="O 0 0 0; H 0 0 1", basis="sto-3g").build()          # odd electron count with spin 0
+    with pytest.raises(KeyError):
+        Mole(atom="O 0 0 0", basis="no-such-basis").build()
+    # BASELINE config sizes
+    from mi355scf import fixtures
+    assert Mole(atom=fixtures.BENZENE, basis="cc-pVTZ").build().nao == 264
+    assert Mole(atom=fixtures.H2CO, basis="6-31G(d)").build().nao == 32
+
+
+def test_contracted_functions_are_normalised():
+    """<chi|chi> = 1 for every packed shell (radial integral with the stored coefficients)."""
+    from mi355scf.mole import Mole, gaussian_int
+    mol = Mole(atom=MOLECULES["h2co"], basis="cc-pvtz").build()
+    for b in mol._bas:
+        l, n, pe, pc = int(b[1]), int(b[2]), int(b[5]), int(b[6])
+        e, c = mol._env[pe:pe + n], mol._env[pc:pc + n]
+        s = sum(ci * cj * gaussian_int(2 * l + 2, ai + aj) for ci, ai in zip(c, e) for cj, aj in zip(c, e))
+        assert abs(s - 1.0) < 1e-12
+
+
+def test_xc_name_parsing():
+    from mi355scf.dft import parse_xc
+    hyb, terms, gga = parse_xc("B3LYP")
+    assert hyb == 0.2 and gga and abs(sum(c for c, _ in terms) - (0.08 + 0.72 + 0.19 + 0.81)) < 1e-15
+    assert parse_xc("pbe")[0] == 0.0 and parse_xc("PBE0")[0] == 0.25 and parse_xc("lda,vwn")[2] is False
+    with pytest.raises(NotImplementedError):
+        parse_xc("M06-2X")
+
+
+def test_grid_tables():
+    from mi355scf import grids
+    r, dr = grids.radial_treutler_ahlrichs(75, 6)
+    assert len(r) == 75 and np.all(np.diff(r) > 0) and np.all(dr > 0)
+    # radial rule integrates exp(-r^2) r^2 -> sqrt(pi)/4
+    assert abs(np.sum(np.exp(-r * r) * r * r * dr) - np.sqrt(np.pi) / 4) < 1e-8
+    for n in (50, 86, 266, 302):
+        x, w = grids.lebedev(n)
+        assert x.shape == (n, 3) and abs(w.sum() - 1) < 1e-13 and np.abs(np.linalg.norm(x, axis=1) - 1).max() < 1e-13
+        assert abs((w * x[:, 0] ** 2 * x[:, 1] ** 2).sum() - 1.0 / 15) < 1e-13      # exact for degree-4 polynomials
+    angs = grids.prune_nwchem(6, r, 302)
+    assert set(angs.tolist()) <= {50, 86, 266, 302} and angs[0] == 50 and 302 in angs
+
+
+def test_smiles_fixtures_and_rdkit_standin():
+    from rdkit import Chem
+    from rdkit.Chem import Descriptors
+    m = Chem.MolFromSmiles("CC(C)Cc1ccc(cc1)C(C)C(=O)O")
+    assert Chem.rdMolDescriptors.CalcMolFormula(m) == "C13H18O2" and abs(Descriptors.MolWt(m) - 206.28) < 0.05
+    mh = Chem.AddHs(m)
+    assert mh.GetNumAtoms() == 33 and m.GetNumAtoms() == 15
+    c60 = Chem.AddHs(Chem.MolFromSmiles("C60")).GetConformer().GetPositions()
+    d = np.linalg.norm(c60[:, None] - c60[None], axis=2) + np.eye(60) * 9
+    assert c60.shape == (60, 3) and abs(d.min() - 1.43) < 1e-6 and np.all((d < 1.44).sum(axis=1) == 3)
+    with pytest.raises(NotImplementedError):
+        Chem.MolFromSmiles("N#N")
+
+
+def test_model_hessian_is_positive_and_invariant():
+    from mi355scf.geomopt import model_hessian
+    from mi355scf.mole import Mole
+    mol = Mole(atom=MOLECULES["c2h4"], basis="sto-3g").build()
+    x = mol.atom_coords()
+    H = model_hessian(mol, x)
+    assert np.allclose(H, H.T) and np.linalg.eigvalsh(H).min() > 0
+    t = np.tile([1.0, 0, 0], mol.natm)                   # a rigid translation only feels the small diagonal shift
+    assert abs(t @ (H - 0.02 * np.eye(len(t))) @ t) < 1e-6
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pyscf import gto, scf
+    from mi355scf.engine import EngineError
+    mol = gto.M(atom="H 0 0 0; H 0 0 0.74", basis="sto-3g", verbose=0)
+    with pytest.raises(EngineError):
+        scf.RHF(mol).kernel()
