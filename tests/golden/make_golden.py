@@ -20,6 +20,19 @@ cases = {
     "h2co_631gd_rhf": (fixtures.H2CO, "6-31g(d)"),
     "benzene_ccpvdz_rhf": (fixtures.BENZENE, "cc-pvdz"),
 }
+dft_cases = {"benzene_ccpvdz_b3lyp": (fixtures.BENZENE, "cc-pvdz", "B3LYP"), "h2o_ccpvdz_b3lyp": (fixtures.H2O, "cc-pvdz", "B3LYP"),
+             "h2o_ccpvdz_pbe": (fixtures.H2O, "cc-pvdz", "PBE")}
+from oracle import dft as odft
+for key, (atom, basis, xc) in dft_cases.items():
+    if key in out and "--force" not in sys.argv:
+        continue
+    mol = Mole(atom=atom, basis=basis).build()
+    t = time.time()
+    r = odft.rks(mol, xc, verbose=True)
+    out[key] = dict(e_tot=r["e_tot"], converged=bool(r["converged"]), cycles=r["cycles"], nao=mol.nao, ngrids=r["ngrids"],
+                    nelec_grid=r["nelec_grid"], xc=xc, seconds=round(time.time() - t, 2), threads=orc.Oracle.num_threads())
+    print(key, out[key])
+    json.dump(out, open(path, "w"), indent=1)
 for key, (atom, basis) in cases.items():
     if key in out and "--force" not in sys.argv:
         continue

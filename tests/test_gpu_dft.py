@@ -107,3 +107,23 @@ def test_rks_energy_matches_oracle(xc, e_mem):
     ref = odft.rks(mol, xc, dm0=mf.get_init_guess())
     assert abs(e - ref["e_tot"]) < 1e-7, (e, ref["e_tot"])
     assert abs(float(mf._nelec_grid) - 10.0) < 1e-5
+
+
+@pytest.mark.parametrize("key,mol_name,xc", [("benzene_ccpvdz_b3lyp", "benzene", "B3LYP"), ("h2o_ccpvdz_pbe", "h2o", "PBE")])
+def test_rks_energy_vs_committed_oracle_golden(key, mol_name, xc):
+    """tests/golden/energies.json (made by tests/golden/make_golden.py with oracle/dft.py)."""
+    import json, os
+    from pyscf import gto, dft
+    from mi355scf import fixtures
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "energies.json")))[key]
+    mol = gto.Mole()
+    mol.atom = fixtures.BENZENE if mol_name == "benzene" else fixtures.H2O
+    mol.basis = "cc-pVDZ"
+    mol.verbose = 0
+    mol.build()
+    mf = dft.RKS(mol).to_gpu()
+    mf.xc = xc
+    e = mf.kernel()
+    assert mf.converged and mf.grids.size == g["ngrids"]
+    assert abs(e - g["e_tot"]) < 2e-7, (e, g["e_tot"])
+    assert abs(float(mf._nelec_grid) - g["nelec_grid"]) < 1e-7
