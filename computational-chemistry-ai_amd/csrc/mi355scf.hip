@@ -2695,3 +2695,68 @@ extern "C" int mi_commutator_norm(mi_ctx *c, const double *d_M, double *d_E, dou
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+// =================================================================================================
+// Vxc accumulation  C[m][n] += sum_g A[m][g] * W[n][g]   (A = ao0, W = weighted AOs; K = grid dimension).
+// rocBLAS runs this shape (tiny M,N ~ N_ao, K ~ 3e4) at < 1 TFLOP/s (no split-K: a handful of workgroups),
+// so it is done here: 64x64 output tile per workgroup, grid.z splits the grid points, row panels staged in
+// LDS (the contraction index is the contiguous one: coalesced loads), v_mfma_f64_16x16x4_f64, 2x2 MFMA tiles
+// per wave, FP64 atomics to combine the splits.
+// =================================================================================================
+#define VM_T 64
+#define VM_KS 64
+__global__ __launch_bounds__(256) void xc_vmat_kernel(const double *__restrict__ A, const double *__restrict__ W, int nao, int64_t ng,
+                                                      int64_t kchunk, double *C)
+{
+    __shared__ double Pa[VM_T][VM_KS + 4], Pb[VM_T][VM_KS + 4];
+    const int m0 = blockIdx.y * VM_T, n0 = blockIdx.x * VM_T;
+    const int64_t kbeg = (int64_t)blockIdx.z * kchunk, kend = min(ng, kbeg + kchunk);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qm = (wave >> 1) * 32, qn = (wave & 1) * 32;
+    d4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int64_t k0 = kbeg; k0 < kend; k0 += VM_KS) {
+        for (int idx = threadIdx.x; idx < VM_T * VM_KS; idx += 256) {
+            int r = idx / VM_KS, k = idx - r * VM_KS;
+            int64_t g = k0 + k;
+            Pa[r][k] = (m0 + r < nao && g < kend) ? A[(size_t)(m0 + r) * ng + g] : 0.0;
+            Pb[r][k] = (n0 + r < nao && g < kend) ? W[(size_t)(n0 + r) * ng + g] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < VM_KS; kk += 4) {
+            const int kc = kk + (lane >> 4);
+            double a0 = Pa[qm + (lane & 15)][kc], a1 = Pa[qm + 16 + (lane & 15)][kc];
+            double b0 = Pb[qn + (lane & 15)][kc], b1 = Pb[qn + 16 + (lane & 15)][kc];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int row = m0 + qm + a * 16 + (lane >> 4) + 4 * r, col = n0 + qn + b * 16 + (lane & 15); // f64 MFMA C/D layout
+                if (row < nao && col < nao) atomicAdd(&C[(size_t)row * nao + col], acc[a][b][r]);
+            }
+}
+
+extern "C" int mi_xc_vmat(mi_ctx *c, const double *d_ao0, const double *d_aow, int64_t ng, double *d_vmat, void *stream)
+{
+    if (!c || !d_ao0 || !d_aow || !d_vmat) return fail("mi_xc_vmat: null argument");
+    const int nt = (c->nao + VM_T - 1) / VM_T;
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>((ng + 511) / 512, (1024 + nt * nt - 1) / (nt * nt)));
+    int64_t kchunk = ((ng + nsplit - 1) / nsplit + VM_KS - 1) / VM_KS * VM_KS;
+    nsplit = (ng + kchunk - 1) / kchunk;
+    hipLaunchKernelGGL(xc_vmat_kernel, dim3(nt, nt, (unsigned)nsplit), dim3(256), 0, (hipStream_t)stream, d_ao0, d_aow, c->nao, ng, kchunk, d_vmat);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -66,6 +66,7 @@ def lib():
         L.mi_xc_rho.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
         L.mi_xc_eval.argtypes = [ip, dp, ctypes.c_int, vp, vp, i64, ctypes.c_int, vp, vp, vp, vp, vp]
         L.mi_xc_aow.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
+        L.mi_xc_vmat.argtypes = [vp, vp, vp, i64, vp, vp]
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_sp2_iterate.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, ctypes.POINTER(vp), vp]
@@ -231,6 +232,9 @@ class Engine:
         aow = self._new(self.nao, ng)
         _check(lib().mi_xc_aow(self._h, ao.data_ptr(), wv.data_ptr(), ng, int(gga), aow.data_ptr(), self._stream()))
         return aow
+
+    def xc_vmat(self, ao0, aow, vmat):
+        _check(lib().mi_xc_vmat(self._h, ao0.data_ptr(), aow.data_ptr(), ao0.shape[-1], vmat.data_ptr(), self._stream()))
 
     # --- row a15: gradient pieces -----------------------------------------------------------------
     def grad_1e(self, D, W, grad):

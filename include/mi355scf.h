@@ -167,6 +167,10 @@ int mi_grad_1e(mi_ctx *ctx, const double *d_D, const double *d_W, double *d_grad
  * round-robin to ranks: the result is a partial sum to be all-reduced by the caller. */
 int mi_grad_eri(mi_ctx *ctx, const double *d_D, double hyb, double *d_grad, void *stream);
 
+/* d_vmat[nao][nao] += ao0 . aow^T over the grid block (split-K FP64 MFMA kernel; rocBLAS has no split-K for
+ * this tiny-M,N / huge-K shape and runs it at < 1 TFLOP/s).  The caller symmetrises (Vxc = vmat + vmat^T). */
+int mi_xc_vmat(mi_ctx *ctx, const double *d_ao0, const double *d_aow, int64_t ng, double *d_vmat, void *stream);
+
 /* Real-solid-harmonic coefficient table used by the kernels: out[ncart(l)][2l+1] (host). */
 int mi_c2s_table(int l, double *out);
 
