@@ -241,7 +241,7 @@ struct mi_ctx {
     int *d_wave_seg = nullptr;           // [nwaves+1] segment range of each wave
     int n_jk_waves = 0;
     double *d_tiles = nullptr;
-    int64_t tile_doubles = 0;
+    int64_t tile_doubles = 0, tile_alloc = 0;
     // J/K work buffers
     double *d_Dpad = nullptr, *d_Jacc = nullptr, *d_Kacc = nullptr;
     int ldp = 0;
@@ -336,8 +336,38 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
     return 0;
 }
 
+// The resident tile store can be ~100 GB; hipMalloc of that size costs 0.1-2 s.  A freed store is parked
+// (one slot per device) and reused by the next context -- e.g. every step of a geometry optimisation.
+struct TileArena { double *ptr = nullptr; int64_t doubles = 0; };
+static TileArena g_arena[16];
+
+static int arena_take(int dev, int64_t need, double **out)
+{
+    TileArena &a = g_arena[dev & 15];
+    if (a.ptr && a.doubles >= need && a.doubles <= need + need / 4 + (1 << 20)) {
+        *out = a.ptr; a.ptr = nullptr; a.doubles = 0;
+        return 0;
+    }
+    if (a.ptr) { hipFree(a.ptr); a.ptr = nullptr; a.doubles = 0; }
+    HIPCHK(hipMalloc((void **)out, sizeof(double) * need));
+    return 0;
+}
+
+static void arena_give(int dev, double *p, int64_t doubles)
+{
+    TileArena &a = g_arena[dev & 15];
+    if (a.ptr) hipFree(a.ptr);
+    a.ptr = p; a.doubles = doubles;
+}
+
+extern "C" void mi_release_cache(void)
+{
+    for (auto &a : g_arena) { if (a.ptr) hipFree(a.ptr); a.ptr = nullptr; a.doubles = 0; }
+}
+
 static void free_eri(mi_ctx *c)
 {
+    if (c->d_tiles) { arena_give(c->device, c->d_tiles, c->tile_alloc); c->d_tiles = nullptr; }
     for (int i = 0; i < NPC; i++) {
         if (c->pc[i].d_recs) hipFree(c->pc[i].d_recs);
         if (c->pc[i].d_q) hipFree(c->pc[i].d_q);
@@ -1154,12 +1184,18 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     }
     size_t freeb = 0, totb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totb));
+    freeb += (size_t)g_arena[c->device & 15].doubles * 8; // a parked store is reusable (or freed) by arena_take
     if ((size_t)off * 8 + ((size_t)1 << 30) > freeb) {
         hipFree(d_work); hipFree(d_comp);
         return fail("resident ERI store needs %.1f GB but only %.1f GB of HBM is free; shard over more GPUs",
                     off * 8e-9, freeb * 1e-9);
     }
-    HIPCHK(hipMalloc(&c->d_tiles, sizeof(double) * std::max<int64_t>(off, 1)));
+    c->tile_alloc = std::max<int64_t>(off, 1);
+    {
+        TileArena &pk = g_arena[c->device & 15];
+        if (pk.ptr && pk.doubles >= c->tile_alloc && pk.doubles <= c->tile_alloc + c->tile_alloc / 4 + (1 << 20)) c->tile_alloc = pk.doubles;
+    }
+    if (arena_take(c->device, c->tile_alloc, &c->d_tiles)) return -1;
     HIPCHK(hipMemsetAsync(c->d_tiles, 0, sizeof(double) * std::max<int64_t>(off, 1), st));
 
     lap("tiles/runs/segments + alloc");

@@ -50,6 +50,7 @@ def lib():
         L.mi_ctx_destroy.argtypes = [vp]
         L.mi_ctx_destroy.restype = None
         L.mi_ctx_nao.argtypes = [vp]
+        L.mi_release_cache.restype = None
         L.mi_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
         L.mi_int1e.argtypes = [vp, vp, vp, vp, vp, dp, vp]
         L.mi_eri_prepare.argtypes = [vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp]
@@ -78,6 +79,11 @@ def lib():
         L.mi_rys_roots_host.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp]
         _lib = L
     return _lib
+
+
+def release_cache():
+    """Free tile stores parked by destroyed contexts (kept for reuse across geometry steps)."""
+    lib().mi_release_cache()
 
 
 def _check(rc):

@@ -41,6 +41,10 @@ int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, int nbas, co
 void mi_ctx_destroy(mi_ctx *ctx);
 int mi_ctx_nao(const mi_ctx *ctx);
 
+/* A destroyed context parks its (possibly ~100 GB) tile store for reuse by the next context on the same
+ * device (geometry optimisation); this frees the parked stores. */
+void mi_release_cache(void);
+
 /* Tunables (project-defined, no reference counterpart), effective at the next mi_eri_prepare:
  * "runmax" tiles per J/K work item (0 = auto), "jk_waves" 0 = one wave per work item, longest first;
  * N > 0 = N waves with equal-cost contiguous shares;
