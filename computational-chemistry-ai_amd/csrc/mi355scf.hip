@@ -1244,6 +1244,8 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             X.check_owner = nranks > 1; X.ni = E.ni; X.nj = E.nj; X.nk = E.nk; X.nl = E.nl;
             int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
             size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
+            if (shm2 > 64 * 1024)
+                HIPCHK(hipFuncSetAttribute((const void *)eri_transform_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
             for (int64_t t0 = 0; t0 < ntask; t0 += per) {
                 int nb = (int)std::min<int64_t>(per, ntask - t0);
                 E.t0 = t0; E.ntask = nb; X.t0 = t0;
