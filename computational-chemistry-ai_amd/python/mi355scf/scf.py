@@ -122,6 +122,8 @@ class SCF:
     eig_method = "sp2"
     sp2_tol = 1e-11
     sp2_fused = True   # small N: one fused HIP launch per SP2 step instead of rocBLAS DGEMM + update kernel
+    _sp2_iters = 24
+    _sp2_validated = False   # True once an iteration count has passed the checked path for this Fock spectrum
     sp2_fused_max = 160  # measured: fused wins at N=114 (0.92 -> 0.80 ms/cycle), rocBLAS wins at N=264
 
     def __init__(self, mol):
@@ -320,10 +322,26 @@ class SCF:
             tr = ws["tr"][off:off + 2].cpu()
             err = float(tr[0] - tr[1])
             if abs(err) < self.sp2_tol and abs(float(tr[0]) - target) < 1e-8:
-                self._sp2_iters = max(8, nit - 2) if attempt == 0 else nit
+                self._sp2_iters = nit
+                self._sp2_validated = True
                 return 2.0 * ws["X"] if self._sp2_orth else 2.0 * (Li.T @ ws["X"] @ Li)
             nit = min(nit + 8, 76)
         return None
+
+    def _sp2_fused_async(self, fo, nocc):
+        """Optimistic SP2: enqueue the purification with the iteration count that worked last cycle and return
+        (D', device traces) WITHOUT a host sync; the caller validates tr(X - X^2) together with the cycle's other
+        scalars and redoes the cycle through the checked path if the count was too small."""
+        eng = self.engine
+        n = fo.shape[0]
+        ws = getattr(self, "_sp2f", None)
+        if ws is None or ws["X"].shape[0] != n:
+            mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
+            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2))
+        nit = min(self._sp2_iters, 76)
+        eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
+        off = eng.sp2_iterate(ws["X"], ws["X2"], nit, float(nocc), ws["work"], ws["tr"])
+        return 2.0 * ws["X"], ws["tr"][off:off + 2]
 
     def make_rdm1(self, mo_coeff=None, mo_occ=None):
         if mo_coeff is None:
@@ -385,7 +403,7 @@ class SCF:
         self._after_density(st, dm, e_last=None, next_cycle=0)
         return st
 
-    def _after_density(self, st, dm, e_last, next_cycle):
+    def _after_density(self, st, dm, e_last, next_cycle, sp2_tr=None, nocc=0):
         """J/K(+XC) for `dm`, new Fock in the orthonormal basis, commutator error, energy, |g|; pushes
         (F', e) into the DIIS history and fetches all scalars of the cycle with ONE device-to-host copy."""
         Li, L, h1 = self._Linv, self._L, self._h1
@@ -401,12 +419,18 @@ class SCF:
         nd = st["diis"].push(fo, e_ao) if next_cycle >= self.diis_start_cycle else 0
         n = fo.shape[0]
         nvo = max((n - st["nocc"]) * st["nocc"], 1)
-        vals = (torch.cat([st["diis"].dots_dev[:nd], scal]) if nd else scal).cpu().numpy()   # the cycle's only host sync
+        parts = ([st["diis"].dots_dev[:nd]] if nd else []) + [scal] + ([sp2_tr] if sp2_tr is not None else [])
+        vals = (torch.cat(parts) if len(parts) > 1 else scal).cpu().numpy()   # the cycle's only host sync
+        if sp2_tr is not None:
+            trx, trx2 = vals[-2], vals[-1]
+            if not (abs(trx - trx2) < self.sp2_tol and abs(trx - nocc) < 1e-8):
+                return False
         e_tot = float(vals[nd]) + st["enuc"]
         # |g| = |2 F_vo| = |[F',D']|_F / sqrt(2), normalised by sqrt(n_vo) like PySCF's get_grad norm [MEM]
         gnorm = float(np.sqrt(max(vals[nd + 1], 0.0))) / np.sqrt(2.0) / np.sqrt(nvo)
         st.update(dm=dm, vhf=fock - h1, fo=fo, dots=vals[:nd], e_tot=e_tot, gnorm=gnorm,
                   de=(e_tot - e_last) if e_last is not None else 0.0)
+        return True
 
     def _step(self, st, use_diis=True, want_mo=False):
         """One SCF cycle: CDIIS extrapolation -> occupied projector (SP2 or eigh) -> density -> J/K ->
@@ -416,7 +440,13 @@ class SCF:
             fo = st["diis"].extrapolate(st["dots"])
         else:
             fo = st["fo"]
-        dmo = self._density_sp2(fo, nocc, orth=True) if (self.eig_method == "sp2" and not want_mo) else None
+        tr_dev = None
+        use_sp2 = self.eig_method == "sp2" and not want_mo
+        if (use_sp2 and self.sp2_fused and fo.shape[0] <= self.sp2_fused_max and self._sp2_validated
+                and 0 < nocc < fo.shape[0] and not st.get("_redo")):
+            dmo, tr_dev = self._sp2_fused_async(fo, nocc)
+        else:
+            dmo = self._density_sp2(fo, nocc, orth=True) if use_sp2 else None
         if dmo is None:
             e, c = torch.linalg.eigh(fo)
             co = c[:, :nocc]
@@ -424,9 +454,27 @@ class SCF:
             st.update(mo_e=e, mo_c=Li.T @ c)
         else:
             st.pop("mo_e", None)
+        saved = (st["dmo"], st["diis"].count) if tr_dev is not None else None
         st["dmo"] = dmo
         dm = Li.T @ dmo @ Li
-        self._after_density(st, dm, e_last=st["e_tot"], next_cycle=st["cycle"] + 1)
+        e_prev = st["e_tot"]
+        ok = self._after_density(st, dm, e_last=e_prev, next_cycle=st["cycle"] + 1, sp2_tr=tr_dev, nocc=nocc)
+        if not ok:
+            # the optimistic purification had not converged: roll the DIIS push back and redo this cycle checked
+            st["dmo"], st["diis"].count = saved
+            st["e_tot"] = e_prev
+            self._sp2_validated = False
+            st["_redo"] = True
+            try:
+                dmo = self._density_sp2(fo, nocc, orth=True)
+                if dmo is None:
+                    e, c = torch.linalg.eigh(fo)
+                    co = c[:, :nocc]
+                    dmo = 2.0 * co @ co.T
+                st["dmo"] = dmo
+                self._after_density(st, Li.T @ dmo @ Li, e_last=e_prev, next_cycle=st["cycle"] + 1)
+            finally:
+                st.pop("_redo", None)
         st["cycle"] += 1
         return st
 
