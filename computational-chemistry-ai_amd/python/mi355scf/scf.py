@@ -301,7 +301,8 @@ class SCF:
             tr = torch.stack([torch.trace(X), torch.trace(X2)]).cpu()
             err = float(tr[0] - tr[1])          # = sum lambda (1 - lambda) >= 0
             if abs(err) < self.sp2_tol and abs(float(tr[0]) - target) < 1e-8:
-                self._sp2_iters = max(8, nit - 2) if attempt == 0 else nit + 2
+                self._sp2_iters = nit
+                self._sp2_validated = True
                 return 2.0 * X if self._sp2_orth else 2.0 * (Li.T @ X @ Li)
             nit += 8
         return None
@@ -340,8 +341,21 @@ class SCF:
             ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2))
         nit = min(self._sp2_iters, 76)
         eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
-        off = eng.sp2_iterate(ws["X"], ws["X2"], nit, float(nocc), ws["work"], ws["tr"])
-        return 2.0 * ws["X"], ws["tr"][off:off + 2]
+        if n <= self.sp2_fused_max and self.sp2_fused:
+            off = eng.sp2_iterate(ws["X"], ws["X2"], nit, float(nocc), ws["work"], ws["tr"])
+            return 2.0 * ws["X"], ws["tr"][off:off + 2]
+        # larger N: rocBLAS DGEMM + fused update kernel per step, still without a host sync
+        buf = getattr(self, "_sp2_buf", None)
+        if buf is None or buf[0].numel() != 2 + n * n:
+            buf = self._sp2_buf = [torch.empty(2 + n * n, dtype=torch.float64, device=fo.device) for _ in range(2)]
+        X, X2, cur = ws["X"], ws["X2"], 0
+        for _ in range(nit):
+            torch.matmul(X, X, out=X2)
+            eng.sp2_update(X, X2, float(nocc), buf[cur])
+            X = buf[cur][2:].view(n, n)
+            cur = 1 - cur
+        torch.matmul(X, X, out=X2)
+        return 2.0 * X, torch.stack([torch.trace(X), torch.trace(X2)])
 
     def make_rdm1(self, mo_coeff=None, mo_occ=None):
         if mo_coeff is None:
@@ -442,8 +456,7 @@ class SCF:
             fo = st["fo"]
         tr_dev = None
         use_sp2 = self.eig_method == "sp2" and not want_mo
-        if (use_sp2 and self.sp2_fused and fo.shape[0] <= self.sp2_fused_max and self._sp2_validated
-                and 0 < nocc < fo.shape[0] and not st.get("_redo")):
+        if use_sp2 and self._sp2_validated and 0 < nocc < fo.shape[0] and not st.get("_redo"):
             dmo, tr_dev = self._sp2_fused_async(fo, nocc)
         else:
             dmo = self._density_sp2(fo, nocc, orth=True) if use_sp2 else None
