@@ -138,3 +138,24 @@ def test_oracle_reproduces_committed_golden_vectors():
     assert np.abs(S - g["S"]).max() < 1e-13 and np.abs(V - g["V"]).max() < 1e-12
     J, K = o.jk(g["D"], tol=0.0)
     assert np.abs(J - g["J"]).max() < 1e-11 and np.abs(K - g["K"]).max() < 1e-11
+
+
+@pytest.mark.parametrize("formula,basis,e_lit,tol", [
+    ("h2o", "cc-pvdz", -76.0268, 1e-4),     # literature RHF at the experimental geometry (r = 0.9572 A, 104.52 deg)
+    ("h2o", "cc-pvtz", -76.0571, 1e-4),     #   (CCCBDB-style tabulations; UNVERIFIED-MEMORY, 4 decimals)
+    ("h2o", "def2-tzvp", -76.0590, 2e-4),
+    ("ch4", "cc-pvdz", -40.1987, 1e-4),     # r(CH) = 1.087 A, T_d
+    ("ch4", "cc-pvtz", -40.2134, 1e-4),
+])
+def test_literature_rhf_energies_pin_the_remembered_tz_tables(formula, basis, e_lit, tol):
+    """A wrong digit in a remembered exponent/coefficient moves these energies by far more than `tol`."""
+    import math
+    from oracle import oracle as orc
+    if formula == "h2o":
+        r, th = 0.9572, math.radians(104.52)
+        atom = f"O 0 0 0; H {r * math.sin(th / 2):.6f} 0 {r * math.cos(th / 2):.6f}; H {-r * math.sin(th / 2):.6f} 0 {r * math.cos(th / 2):.6f}"
+    else:
+        a = 0.6276
+        atom = f"C 0 0 0; H {a} {a} {a}; H {-a} {-a} {a}; H {-a} {a} {-a}; H {a} {-a} {-a}"
+    res = orc.rhf(_mol(atom, basis))
+    assert res["converged"] and abs(res["e_tot"] - e_lit) < tol, res["e_tot"]
