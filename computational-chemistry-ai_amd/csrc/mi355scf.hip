@@ -1952,17 +1952,28 @@ extern "C" int mi_xc_aow(mi_ctx *c, const double *d_ao, const double *d_wv, int6
 // SP2 density-matrix purification helpers (row a11 without a diagonalisation): the X*X products are
 // rocBLAS DGEMMs; these kernels fuse everything else so one purification step is 2 launches.
 // =================================================================================================
-// bounds[0] = min_i (F_ii - R_i), bounds[1] = max_i (F_ii + R_i)   (Gershgorin), one block
-__global__ __launch_bounds__(256) void sp2_bounds_kernel(const double *F, int n, double *bounds)
+// Gershgorin discs, one wave per row (coalesced): rows[r] = F_rr - R_r, rows[n + r] = F_rr + R_r
+__global__ __launch_bounds__(256) void sp2_bounds_kernel(const double *F, int n, double *rows)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    double s = 0.0;
+    for (int c = lane; c < n; c += 64) s += fabs(F[(size_t)r * n + c]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        double d = F[(size_t)r * n + r];
+        s -= fabs(d);
+        rows[r] = d - s;
+        rows[n + r] = d + s;
+    }
+}
+
+// X0 = (emax I - F) / (emax - emin); every block reduces the 2n disc bounds itself (cheap, no extra launch)
+__global__ __launch_bounds__(256) void sp2_init_kernel(const double *F, const double *rows, int n, double *X)
 {
     __shared__ double smin[256], smax[256];
     double lo = 1e300, hi = -1e300;
-    for (int r = threadIdx.x; r < n; r += 256) {
-        double d = F[(size_t)r * n + r], s = 0.0;
-        for (int c = 0; c < n; c++) s += fabs(F[(size_t)r * n + c]);
-        s -= fabs(d);
-        lo = fmin(lo, d - s); hi = fmax(hi, d + s);
-    }
+    for (int r = threadIdx.x; r < n; r += 256) { lo = fmin(lo, rows[r]); hi = fmax(hi, rows[n + r]); }
     smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -1972,15 +1983,10 @@ __global__ __launch_bounds__(256) void sp2_bounds_kernel(const double *F, int n,
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { bounds[0] = smin[0]; bounds[1] = smax[0]; }
-}
-
-__global__ __launch_bounds__(256) void sp2_init_kernel(const double *F, const double *bounds, int n, double *X)
-{
+    const double emin = smin[0], emax = smax[0];
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)n * n) return;
     int r = (int)(idx / n), c = (int)(idx - (size_t)r * n);
-    double emin = bounds[0], emax = bounds[1];
     X[idx] = ((r == c ? emax : 0.0) - F[idx]) / (emax - emin);
 }
 
@@ -2013,7 +2019,7 @@ extern "C" int mi_sp2_init(mi_ctx *c, const double *d_F, double *d_X, double *d_
     if (!c || !d_F || !d_X || !d_work) return fail("mi_sp2_init: null argument");
     int n = c->nao;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sp2_bounds_kernel, dim3(1), dim3(256), 0, st, d_F, n, d_work);
+    hipLaunchKernelGGL(sp2_bounds_kernel, dim3((n + 3) / 4), dim3(256), 0, st, d_F, n, d_work);
     hipLaunchKernelGGL(sp2_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, d_F, d_work, n, d_X);
     HIPCHK(hipGetLastError());
     return 0;

@@ -314,7 +314,7 @@ class SCF:
         ws = getattr(self, "_sp2f", None)
         if ws is None or ws["X"].shape[0] != n:
             mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
-            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2))
+            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2 * n))
         nit = min(getattr(self, "_sp2_iters", 24), 72)
         target = float(nocc)
         for attempt in range(5):
@@ -338,7 +338,7 @@ class SCF:
         ws = getattr(self, "_sp2f", None)
         if ws is None or ws["X"].shape[0] != n:
             mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
-            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2))
+            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2 * n))
         nit = min(self._sp2_iters, 76)
         eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
         if n <= self.sp2_fused_max and self.sp2_fused:

@@ -107,7 +107,7 @@ int mi_diis_dots_dev(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int
 
 /* ---- density from the Fock matrix without diagonalisation (row a11) ----------------------------- */
 /* SP2 purification (Niklasson 2002) in an orthonormal basis; the X*X products are the caller's DGEMMs.
- * mi_sp2_init: X0 = (emax*I - F)/(emax - emin) with Gershgorin bounds; d_work: >= 2 doubles.
+ * mi_sp2_init: X0 = (emax*I - F)/(emax - emin) with Gershgorin bounds; d_work: >= 2*n doubles.
  * mi_sp2_update: given X and X2 = X*X writes {tr X, tr X2, X_next[n*n]} to d_out_with_traces, where
  * X_next = X2 if |tr X2 - n_occ| < |2 tr X - tr X2 - n_occ| else 2X - X2.
  * Stand in for the LAPACK eig inside PySCF's SCF.eig (templates/calculate_energy.py:155 -> kernel()). */
