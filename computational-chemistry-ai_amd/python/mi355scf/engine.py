@@ -182,8 +182,11 @@ class Engine:
         squeeze = dm.dim() == 2
         if squeeze:
             dm = dm.unsqueeze(0)
-        J = torch.empty_like(dm) if with_j else None
-        K = torch.empty_like(dm) if with_k else None
+        # J and K are views of ONE buffer so that a sharded run can all-reduce [J|K] in place with one collective
+        buf = torch.empty((int(with_j) + int(with_k),) + tuple(dm.shape), dtype=torch.float64, device=self.device)
+        J = buf[0] if with_j else None
+        K = buf[int(with_j)] if with_k else None
+        self.last_jk_buffer = buf
         with torch.cuda.device(self.device):
             _check(lib().mi_build_jk(self._h, dm.data_ptr(), dm.shape[0], J.data_ptr() if with_j else None,
                                      K.data_ptr() if with_k else None, self._stream()))

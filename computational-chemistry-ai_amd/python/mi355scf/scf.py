@@ -230,6 +230,10 @@ class SCF:
             J, K = self._jk_streamed(dm, with_j, with_k)
         else:
             J, K = self.engine.get_jk(dm, with_j, with_k)
+            if self._nranks > 1:
+                from . import parallel
+                parallel.all_reduce_sum(self.engine.last_jk_buffer, self._pg)   # [J|K] in place, one collective
+            return J, K
         if self._nranks > 1:
             from . import parallel
             parallel.all_reduce_fused([x for x in (J, K) if x is not None], self._pg)
