@@ -1426,6 +1426,7 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
 
 
 
+
 __global__ void pad_density_kernel(const double *D, double *Dp, int nao, int ld)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -13,6 +13,9 @@ for basis in (sys.argv[1:] or ["cc-pVDZ", "cc-pVTZ"]):
     rng = np.random.default_rng(0)
     a = rng.normal(size=(n, n)); D = torch.as_tensor(a + a.T, device="cuda")
     eng = Engine(mol)
+    for kv in os.environ.get("JK_OPTS", "").split(","):
+        if "=" in kv:
+            eng.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     st = eng.prepare_eri(1e-13)
     alg = 8.0 * st["n_unique_eri"] + 24.0 * n * n
     J, K = eng.get_jk(D)
