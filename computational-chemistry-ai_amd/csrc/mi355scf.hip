@@ -1449,7 +1449,8 @@ static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
     JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao};
     if (c->n_tiles == 0) return 0;
     dim3 g(A.nruns), b(64);
-    const bool nt = c->opt_jk_nt != 0;
+    // nontemporal loads only when the tensor cannot stay in the 256 MiB Infinity Cache between SCF cycles
+    const bool nt = c->opt_jk_nt != 0 && (c->opt_jk_nt > 1 || c->tile_doubles * 8 > ((int64_t)256 << 20));
     if (wj && wk) { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<true, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<true, true, false>), g, b, 0, st, A); }
     else if (wj) hipLaunchKernelGGL((jk_tiles_kernel<true, false, true>), g, b, 0, st, A);
     else hipLaunchKernelGGL((jk_tiles_kernel<false, true, true>), g, b, 0, st, A);
