@@ -105,6 +105,11 @@ class Gradients:
             de = de + self.grad_xc(dm)
             torch.cuda.synchronize()
             tm["grad_xc"] = time.time() - t0
+        if mf._nranks > 1:
+            from . import parallel
+            dt = torch.as_tensor(de, device=eng.device)
+            parallel.broadcast0(dt, mf._pg)
+            de = dt.cpu().numpy()
         self.timing = tm
         mf._log(4, "gradient timings (s): " + ", ".join(f"{k} {v:.3f}" for k, v in tm.items()))
         self.de = de

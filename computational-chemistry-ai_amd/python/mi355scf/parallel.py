@@ -59,3 +59,19 @@ def split_range(n, rank, nranks):
     """Contiguous, exhaustive, non-overlapping split of range(n)."""
     per = (n + nranks - 1) // nranks
     return min(rank * per, n), min((rank + 1) * per, n)
+
+
+def broadcast0(t, group=None):
+    """Make rank 0's copy of a (device or host) tensor authoritative on every rank.  Used for the handful of
+    scalars that steer control flow (energy, |g|, DIIS Gram row, SP2 traces, nuclear gradient): replicated
+    FP64 work can differ in the last bit between ranks (atomic summation order), and a borderline convergence
+    test must not let one rank leave a loop whose body contains a collective."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src=0, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=0, group=group)
+    return t

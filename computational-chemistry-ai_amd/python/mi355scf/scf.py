@@ -438,7 +438,11 @@ class SCF:
         n = fo.shape[0]
         nvo = max((n - st["nocc"]) * st["nocc"], 1)
         parts = ([st["diis"].dots_dev[:nd]] if nd else []) + [scal] + ([sp2_tr] if sp2_tr is not None else [])
-        vals = (torch.cat(parts) if len(parts) > 1 else scal).cpu().numpy()   # the cycle's only host sync
+        packed = torch.cat(parts) if len(parts) > 1 else scal
+        if self._nranks > 1:
+            from . import parallel
+            parallel.broadcast0(packed, self._pg)     # identical control flow on every rank
+        vals = packed.cpu().numpy()                    # the cycle's only host sync
         if sp2_tr is not None:
             trx, trx2 = vals[-2], vals[-1]
             if not (abs(trx - trx2) < self.sp2_tol and abs(trx - nocc) < 1e-8):
