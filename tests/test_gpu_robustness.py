@@ -47,3 +47,22 @@ def test_max_cycle_exhaustion_is_not_an_exception():
     assert mf.converged is False and np.isfinite(e)
     dm = mf.make_rdm1()
     assert abs(np.trace(dm @ mf.get_ovlp()) - mol.nelectron) < 1e-8
+
+
+@pytest.mark.parametrize("atom,charge", [("O 0 0 0; H 0 0 0.97", -1),
+                                         ("O 0 0 0.1; H 0.94 0 -0.2; H -0.47 0.81 -0.2; H -0.47 -0.81 -0.2", +1)])
+def test_charged_closed_shell_species_match_oracle(atom, charge):
+    """mol.charge flows through nelectron/occupations; the neutral-atom guess is repaired by the first cycle."""
+    from pyscf import gto, scf
+    from oracle import oracle as orc
+    mol = gto.Mole()
+    mol.atom = atom
+    mol.basis = "6-31g*"
+    mol.charge = charge
+    mol.verbose = 0
+    mol.build()
+    mf = scf.RHF(mol)
+    e = mf.kernel()
+    ref = orc.rhf(mol)
+    assert mf.converged and ref["converged"] and abs(e - ref["e_tot"]) < 1e-8
+    assert mf.mo_occ.sum() == mol.nelectron
