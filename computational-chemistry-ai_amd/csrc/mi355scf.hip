@@ -2765,14 +2765,31 @@ __global__ __launch_bounds__(256) void xc_vmat_kernel(const double *__restrict__
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
-    for (int64_t k0 = kbeg; k0 < kend; k0 += VM_KS) {
-        for (int idx = threadIdx.x; idx < VM_T * VM_KS; idx += 256) {
+    // register-staged software pipeline: the global loads of sub-chunk c+1 are in flight while sub-chunk c is
+    // multiplied out of LDS
+    constexpr int PER = VM_T * VM_KS / 256; // 16 elements of each panel per thread
+    double ra[PER], rb[PER];
+    auto gload = [&](int64_t k0) {
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            int idx = u * 256 + threadIdx.x;
             int r = idx / VM_KS, k = idx - r * VM_KS;
             int64_t g = k0 + k;
-            Pa[r][k] = (m0 + r < nao && g < kend) ? A[(size_t)(m0 + r) * ng + g] : 0.0;
-            Pb[r][k] = (n0 + r < nao && g < kend) ? W[(size_t)(n0 + r) * ng + g] : 0.0;
+            ra[u] = (m0 + r < nao && g < kend) ? A[(size_t)(m0 + r) * ng + g] : 0.0;
+            rb[u] = (n0 + r < nao && g < kend) ? W[(size_t)(n0 + r) * ng + g] : 0.0;
+        }
+    };
+    if (kbeg < kend) gload(kbeg);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += VM_KS) {
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            int idx = u * 256 + threadIdx.x;
+            int r = idx / VM_KS, k = idx - r * VM_KS;
+            Pa[r][k] = ra[u];
+            Pb[r][k] = rb[u];
         }
         __syncthreads();
+        if (k0 + VM_KS < kend) gload(k0 + VM_KS);
 #pragma unroll 4
         for (int kk = 0; kk < VM_KS; kk += 4) {
             const int kc = kk + (lane >> 4);
