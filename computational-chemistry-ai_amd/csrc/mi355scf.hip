@@ -2349,73 +2349,83 @@ struct GradXfArgs {
     double *grad;
     int inv_from_second; // translational invariance: 1: the skipped shell is dp.sh_j, 0: it is cd.sh_i
     int natm3;           // grad points to GRAD_COPIES private copies of [natm*3] (atomic contention relief)
+    int64_t nbatch;      // tasks in this launch
 };
 #define GRAD_COPIES 4096
 
+template <int GSZ> // lanes per quartet: 64, or 16 (four quartets per wave) for the small angular classes
 __global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
 {
     // sum_{x-independent part first}:  g[x] = sum_{r,e} M^x[r][e] * Z[r][e],  Z[r][e] = sum_f E0[e][f] Y[r][f],
     // Y[r][f] = sum_c G[r][c] Mcd[c][f]  -- contracting the two-particle density FIRST makes the work
     // independent of the derivative direction (3x fewer flops than forming the derivative integrals).
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    int ib, ik;
-    find_task(A.prefix, A.nbra, A.t0 + blockIdx.x, ib, ik);
-    const bool same_pair = A.same_class && ib == ik;
-    if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
-    const PairRec dp = A.dplus[ib], cd = A.ket[ik];
+    extern __shared__ double lds_all[];
+    constexpr int QPW = 64 / GSZ;
+    const int grp = threadIdx.x / GSZ, lane = threadIdx.x % GSZ;
+    const int64_t tl = (int64_t)blockIdx.x * QPW + grp; // task index inside this batch
+    const bool live = tl < A.nbatch;
     const bool has_m = A.dminus != nullptr && A.ne_m > 0;
     const int nsab = A.ns1 * A.ns2, nf = A.nf;
+    const size_t region = (size_t)A.ne_p * nf + (has_m ? (size_t)A.ne_m * nf : 0) + (size_t)nsab * A.nscd + (size_t)nsab * nf;
+    double *lds = lds_all + (size_t)grp * region;
     double *E0p = lds;                                        // [ne_p][nf]
     double *E0m = E0p + (size_t)A.ne_p * nf;                  // [ne_m][nf]
     double *G = E0m + (has_m ? (size_t)A.ne_m * nf : 0);      // [nsab][nscd]
     double *Y = G + (size_t)nsab * A.nscd;                    // [nsab][nf]
-    const double *gp = A.work_p + (size_t)blockIdx.x * A.ncomp_p;
-    for (int c = lane; c < A.ne_p * nf; c += 64) E0p[c] = gp[c];
+    int ib = 0, ik = 0;
+    if (live) find_task(A.prefix, A.nbra, A.t0 + tl, ib, ik);
+    const bool same_pair = A.same_class && ib == ik;
+    if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
+    const PairRec dp = A.dplus[ib], cd = A.ket[ik];
     int m_off_m = 0;
-    if (has_m) {
-        const PairRec dm = A.dminus[ib];
-        m_off_m = dm.m_off;
-        const double *gm = A.work_m + (size_t)blockIdx.x * A.ncomp_m;
-        for (int c = lane; c < A.ne_m * nf; c += 64) E0m[c] = gm[c];
-    }
     const double *D = A.D;
     const int ld = A.ld;
-    for (int o = lane; o < nsab * A.nscd; o += 64) {
-        int r = o / A.nscd, c = o - r * A.nscd;
-        int sa = r / A.ns2, sb = r - sa * A.ns2, sc = c / A.nsd, sd = c - sc * A.nsd;
-        int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
-        G[o] = D[(size_t)i * ld + j] * D[(size_t)k * ld + l] -
-               0.25 * A.hyb * (D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k]);
+    if (live) {
+        const double *gp = A.work_p + (size_t)tl * A.ncomp_p;
+        for (int c = lane; c < A.ne_p * nf; c += GSZ) E0p[c] = gp[c];
+        if (has_m) {
+            m_off_m = A.dminus[ib].m_off;
+            const double *gm = A.work_m + (size_t)tl * A.ncomp_m;
+            for (int c = lane; c < A.ne_m * nf; c += GSZ) E0m[c] = gm[c];
+        }
+        for (int o = lane; o < nsab * A.nscd; o += GSZ) {
+            int r = o / A.nscd, c = o - r * A.nscd;
+            int sa = r / A.ns2, sb = r - sa * A.ns2, sc = c / A.nsd, sd = c - sc * A.nsd;
+            int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
+            G[o] = D[(size_t)i * ld + j] * D[(size_t)k * ld + l] -
+                   0.25 * A.hyb * (D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k]);
+        }
     }
     __syncthreads();
-    const double *Mcd = A.Mbuf + cd.m_off;
-    for (int o = lane; o < nsab * nf; o += 64) {
-        int r = o / nf, f = o - r * nf;
-        double s = 0.0;
-        for (int c = 0; c < A.nscd; c++) s += G[r * A.nscd + c] * Mcd[c * nf + f];
-        Y[o] = s;
+    if (live) {
+        const double *Mcd = A.Mbuf + cd.m_off;
+        for (int o = lane; o < nsab * nf; o += GSZ) {
+            int r = o / nf, f = o - r * nf;
+            double s = 0.0;
+            for (int c = 0; c < A.nscd; c++) s += G[r * A.nscd + c] * Mcd[c * nf + f];
+            Y[o] = s;
+        }
     }
     __syncthreads();
     double acc[3] = {0.0, 0.0, 0.0};
-    {
+    if (live) {
         const double *Mp = A.Mbuf + dp.m_off;
         const size_t xs = (size_t)nsab * A.ne_p;
-        for (int o = lane; o < nsab * A.ne_p; o += 64) {
+        for (int o = lane; o < nsab * A.ne_p; o += GSZ) {
             int r = o / A.ne_p, e = o - r * A.ne_p;
             double z = 0.0;
             for (int f = 0; f < nf; f++) z += E0p[e * nf + f] * Y[r * nf + f];
             acc[0] += Mp[o] * z; acc[1] += Mp[xs + o] * z; acc[2] += Mp[2 * xs + o] * z;
         }
-    }
-    if (has_m) {
-        const double *Mm = A.Mbuf + m_off_m;
-        const size_t xs = (size_t)nsab * A.ne_m;
-        for (int o = lane; o < nsab * A.ne_m; o += 64) {
-            int r = o / A.ne_m, e = o - r * A.ne_m;
-            double z = 0.0;
-            for (int f = 0; f < nf; f++) z += E0m[e * nf + f] * Y[r * nf + f];
-            acc[0] += Mm[o] * z; acc[1] += Mm[xs + o] * z; acc[2] += Mm[2 * xs + o] * z;
+        if (has_m) {
+            const double *Mm = A.Mbuf + m_off_m;
+            const size_t xm = (size_t)nsab * A.ne_m;
+            for (int o = lane; o < nsab * A.ne_m; o += GSZ) {
+                int r = o / A.ne_m, e = o - r * A.ne_m;
+                double z = 0.0;
+                for (int f = 0; f < nf; f++) z += E0m[e * nf + f] * Y[r * nf + f];
+                acc[0] += Mm[o] * z; acc[1] += Mm[xm + o] * z; acc[2] += Mm[2 * xm + o] * z;
+            }
         }
     }
     double w = 4.0;
@@ -2424,9 +2434,9 @@ __global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
     if (same_pair) w *= 0.5;
     for (int x = 0; x < 3; x++) {
         double v = acc[x];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) {
-            double *gc = A.grad + (size_t)(blockIdx.x & (GRAD_COPIES - 1)) * A.natm3;
+        for (int o = GSZ / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (live && lane == 0) {
+            double *gc = A.grad + (size_t)((blockIdx.x * QPW + grp) & (GRAD_COPIES - 1)) * A.natm3;
             atomicAdd(&gc[A.shell_atom[dp.sh_i] * 3 + x], w * v);
             // the skipped permutation (derivative on the first shell of the bra pair P) by invariance
             atomicAdd(&gc[A.shell_atom[A.inv_from_second ? dp.sh_j : cd.sh_i] * 3 + x], -w * v);
@@ -2533,6 +2543,9 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                 X.inv_from_second = swap ? 0 : 1;
                 size_t shm = sizeof(double) * ((size_t)X.ne_p * X.nf + (size_t)X.ne_m * X.nf + (size_t)X.ns1 * X.ns2 * (X.nf + X.nscd));
                 if (shm > 160 * 1024) return fail("gradient contraction needs %zu bytes of LDS", shm);
+                const bool dbg = getenv("MI355_DEBUG") != nullptr;
+                auto tc0 = std::chrono::steady_clock::now();
+                if (dbg) hipStreamSynchronize(st);
                 int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / Ep.ncomp), (int64_t)1 << 21);
                 if (c->nranks > 1) per = std::min<int64_t>(per, std::max<int64_t>(1024, ntask / (8 * c->nranks)));
                 for (int64_t t0 = 0; t0 < ntask; t0 += per) {
@@ -2541,11 +2554,21 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                     Ep.t0 = t0; Ep.ntask = nb;
                     if (launch_eri(c, Ep, nb, st)) return -1;
                     if (has_m) { Em.t0 = t0; Em.ntask = nb; if (launch_eri(c, Em, nb, st)) return -1; }
-                    X.t0 = t0;
-                    if (shm > 64 * 1024)
-                        HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                    hipLaunchKernelGGL(eri_grad_contract, dim3(nb), dim3(64), shm, st, X);
+                    X.t0 = t0; X.nbatch = nb;
+                    const int big = std::max({X.ns1 * X.ns2 * X.nscd, X.ns1 * X.ns2 * X.nf, X.ns1 * X.ns2 * X.ne_p});
+                    if (big <= 48 && shm * 4 <= 64 * 1024) { // small classes: four quartets per wave (16 lanes each)
+                        hipLaunchKernelGGL(eri_grad_contract<16>, dim3((nb + 3) / 4), dim3(64), shm * 4, st, X);
+                    } else {
+                        if (shm > 64 * 1024)
+                            HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                        hipLaunchKernelGGL(eri_grad_contract<64>, dim3(nb), dim3(64), shm, st, X);
+                    }
                     HIPCHK(hipGetLastError());
+                }
+                if (dbg) {
+                    hipStreamSynchronize(st);
+                    fprintf(stderr, "[mi355] grad class (%d%d|%d%d) perm %d: %ld quartets, %.3f s\n", l1, l2, lc, ldd, perm, (long)ntask,
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count());
                 }
             }
         }
