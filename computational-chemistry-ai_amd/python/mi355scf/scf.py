@@ -145,6 +145,27 @@ class SCF:
         self._rank, self._nranks, self._pg = 0, 1, None
         self._stream_groups = 1   # >1: direct mode (ERI tile groups recomputed each Fock build)
         self.timing = {}
+        self._auto_shard()
+
+    def _auto_shard(self):
+        """Under `torchrun` (WORLD_SIZE > 1) every SCF object shards itself over the default process group, so an
+        unchanged script (`torchrun --nproc-per-node 8 calculate_energy.py ... --use-gpu`) runs on 8 GPUs: one
+        process per GPU, RCCL all-reduce of the Fock contributions.  Set MI355_AUTO_SHARD=0 to disable."""
+        import os
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1 or os.environ.get("MI355_AUTO_SHARD", "1") == "0":
+            return
+        from . import parallel
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            ndev = max(torch.cuda.device_count(), 1)
+            backend = os.environ.get("MI355_DIST_BACKEND", "nccl")
+            torch.cuda.set_device(local if backend == "nccl" else local % ndev)
+            parallel.init(backend, torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else None)
+        self.shard(dist.get_rank(), dist.get_world_size())
+        if dist.get_rank() != 0:
+            self.verbose = min(self.verbose, 0)   # one log stream
 
     # --- backend selection (row a14) ------------------------------------------------------------
     def to_gpu(self):
