@@ -778,6 +778,17 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
     for (int c = lane; c < A.ne * A.nf; c += 64) E0[c] = E0g[c];
     __syncthreads();
     const double *Mab = A.Mbuf + ab.m_off, *Mcd = A.Mbuf + cd.m_off;
+    // which of the 8 index images can land in a canonical tile (I >= J, K >= L) at all: decided once per quartet
+    // from the block ranges of the four shells (necessary condition; put_tile still checks each element)
+    unsigned mask;
+    {
+        const int ni = A.nsab / A.nsb, nj = A.nsb, nk = A.nscd / A.nsd, nl = A.nsd;
+        const int lo[4] = {ab.ao_i >> 3, ab.ao_j >> 3, cd.ao_i >> 3, cd.ao_j >> 3};
+        const int hi[4] = {(ab.ao_i + ni - 1) >> 3, (ab.ao_j + nj - 1) >> 3, (cd.ao_i + nk - 1) >> 3, (cd.ao_j + nl - 1) >> 3};
+        auto ok = [&](int a, int b, int c, int d) { return hi[a] >= lo[b] && hi[c] >= lo[d]; };
+        mask = (ok(0, 1, 2, 3) ? 1u : 0u) | (ok(1, 0, 2, 3) ? 2u : 0u) | (ok(0, 1, 3, 2) ? 4u : 0u) | (ok(1, 0, 3, 2) ? 8u : 0u) |
+               (ok(2, 3, 0, 1) ? 16u : 0u) | (ok(3, 2, 0, 1) ? 32u : 0u) | (ok(2, 3, 1, 0) ? 64u : 0u) | (ok(3, 2, 1, 0) ? 128u : 0u);
+    }
     for (int o = lane; o < A.nsab * A.nf; o += 64) {
         int r = o / A.nf, f = o - r * A.nf;
         double s = 0.0;
@@ -791,8 +802,14 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
         for (int f = 0; f < A.nf; f++) s += X[r * A.nf + f] * Mcd[c * A.nf + f];
         int sa = r / A.nsb, sb = r - sa * A.nsb, sc = c / A.nsd, sd = c - sc * A.nsd;
         int i = ab.ao_i + sa, j = ab.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
-        put_tile(A, i, j, k, l, s); put_tile(A, j, i, k, l, s); put_tile(A, i, j, l, k, s); put_tile(A, j, i, l, k, s);
-        put_tile(A, k, l, i, j, s); put_tile(A, l, k, i, j, s); put_tile(A, k, l, j, i, s); put_tile(A, l, k, j, i, s);
+        if (mask & 1) put_tile(A, i, j, k, l, s);
+        if (mask & 2) put_tile(A, j, i, k, l, s);
+        if (mask & 4) put_tile(A, i, j, l, k, s);
+        if (mask & 8) put_tile(A, j, i, l, k, s);
+        if (mask & 16) put_tile(A, k, l, i, j, s);
+        if (mask & 32) put_tile(A, l, k, i, j, s);
+        if (mask & 64) put_tile(A, k, l, j, i, s);
+        if (mask & 128) put_tile(A, l, k, j, i, s);
     }
 }
 
