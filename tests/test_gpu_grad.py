@@ -144,3 +144,30 @@ def test_total_b3lyp_gradient_close_to_finite_difference():
     g = mf.nuc_grad_method().kernel()
     ref = FDGradients(mf).kernel()
     assert np.abs(g - ref).max() < 2e-4, (g, ref)
+
+
+def test_rhf_gradient_matches_cpu_oracle_finite_difference():
+    """Independent check: GPU analytic gradient vs central differences of the CPU ORACLE's RHF energy."""
+    from pyscf import gto, scf
+    from oracle import oracle as orc
+    mol = gto.Mole()
+    mol.atom = MOLECULES["h2o"]
+    mol.basis = "6-31g*"
+    mol.verbose = 0
+    mol.build()
+    mf = scf.RHF(mol)
+    mf.conv_tol = 1e-11
+    mf.kernel()
+    g = mf.nuc_grad_method().kernel()
+    R = mol.atom_coords()
+    h = 1e-3
+    ref = np.zeros_like(R)
+    for ia in range(mol.natm):
+        for x in range(3):
+            e = []
+            for sgn in (+1, -1):
+                Rn = R.copy()
+                Rn[ia, x] += sgn * h
+                e.append(orc.rhf(mol.set_geom_(Rn, unit="Bohr", inplace=False), conv_tol=1e-12)["e_tot"])
+            ref[ia, x] = (e[0] - e[1]) / (2 * h)
+    assert np.abs(g - ref).max() < 2e-6, (g, ref)
