@@ -79,7 +79,8 @@ class RKS(RHF):
         nelec = torch.zeros((), dtype=torch.float64, device=eng.device)
         exc = torch.zeros((), dtype=torch.float64, device=eng.device)
         lo, hi = self._grid_range(ng)
-        B = self.grid_block
+        # grid block: as large as a ~1.5 GB working set allows (fewer launches for small molecules), at least grid_block
+        B = max(self.grid_block, int(1.5e9 / (48.0 * n)) // 1024 * 1024)
         cache = self._ao_cache_for(n, hi - lo, 4 if gga else 1)
         for ib, p0 in enumerate(range(lo, hi, B)):
             p1 = min(p0 + B, hi)
