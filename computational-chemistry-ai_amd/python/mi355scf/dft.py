@@ -45,6 +45,7 @@ class RKS(RHF):
     xc = "LDA,VWN"
     grid_block = 32768
     cache_ao = True
+    small_rho_cutoff = 1e-7   # PySCF RKS default [MEM]
 
     def __init__(self, mol, xc=None):
         super().__init__(mol)
@@ -56,6 +57,7 @@ class RKS(RHF):
     def reset(self, mol=None):
         super().reset(mol)
         self.grids = Grids(self.mol)
+        self._pruned = False
         lvl = getattr(self, "_grid_level", None)
         if lvl is not None:
             self.grids.level = lvl
@@ -117,7 +119,35 @@ class RKS(RHF):
         from . import parallel
         return parallel.split_range(ng, self._rank, self._nranks)
 
+    def _prune_small_rho_grids(self, dm):
+        """Drop grid points whose |rho * w| is below small_rho_cutoff / n_grid for the first density the SCF sees
+        (PySCF `rks.prune_small_rho_grids_`, applied once in `get_veff` when the grid integrates the electron count to
+        1 % [MEM]).  Evaluated on all points on every rank (one-off), so sharded runs prune identically."""
+        self._pruned = True
+        if not self.small_rho_cutoff or self.small_rho_cutoff <= 1e-20:
+            return
+        eng = self.engine
+        coords, weights = self.grids.coords, self.grids.weights
+        ng = coords.shape[0]
+        rho = torch.empty(ng, dtype=torch.float64, device=eng.device)
+        B = max(self.grid_block, int(1.5e9 / (16.0 * eng.nao)) // 1024 * 1024)
+        for p0 in range(0, ng, B):
+            p1 = min(p0 + B, ng)
+            ao = eng.eval_ao(coords[p0:p1], deriv=0)
+            rho[p0:p1] = eng.xc_rho(ao, dm @ ao[0], deriv=0)[0]
+        n = float(torch.dot(rho, weights))
+        if abs(n - self.mol.nelectron) < 0.01 * n:
+            keep = (rho * weights).abs() > self.small_rho_cutoff / ng
+            nkeep = int(keep.sum())
+            self._log(4, f"Drop grids {ng - nkeep}")
+            self.grids.coords = coords[keep].contiguous()
+            self.grids.weights = weights[keep].contiguous()
+            if self.grids.atom_of is not None:
+                self.grids.atom_of = self.grids.atom_of[keep.cpu().numpy()]
+
     def _fock_energy(self, dm, scal):
+        if not getattr(self, "_pruned", False):
+            self._prune_small_rho_grids(dm)
         nelec, exc, vxc, hyb = self._xc_reduced(dm)
         self._nelec_grid = nelec
         if abs(hyb) > 1e-12:

@@ -313,12 +313,25 @@ def nr_rks(mol, coords, weights, xc, dm, block=20000, rho_cut=1e-10):
     return nelec, exc, vmat + vmat.T, hyb
 
 
-def rks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-9, max_cycle=50, verbose=False):
+def rks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-9, max_cycle=50, verbose=False, small_rho_cutoff=1e-7):
     coords, weights = build_grids(mol, level)
     o = orc.Oracle(mol)
     info = {}
+    grid = {"c": coords, "w": weights, "pruned": small_rho_cutoff <= 1e-20}
 
     def veff(dm):
+        if not grid["pruned"]:
+            # PySCF rks.prune_small_rho_grids_ [MEM]: once, with the first density, if the grid integrates N_elec to 1 %
+            grid["pruned"] = True
+            c, w = grid["c"], grid["w"]
+            rho = np.concatenate([np.einsum("gi,ij,gj->g", a, dm, a) for a in
+                                  (eval_ao(mol, c[p:p + 20000], 0)[0] for p in range(0, len(c), 20000))])
+            n = float(rho @ w)
+            if abs(n - mol.nelectron) < 0.01 * n:
+                keep = np.abs(rho * w) > small_rho_cutoff / len(w)
+                grid["c"], grid["w"] = c[keep], w[keep]
+        coords, weights = grid["c"], grid["w"]
+        info["ngrids"] = len(weights)
         n, exc, vxc, hyb = nr_rks(mol, coords, weights, xc, dm)
         J, K = o.jk(dm)
         info["nelec"] = n
@@ -331,5 +344,5 @@ def rks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-9, max_cycle=50, verbose
 
     r = orc.rhf(mol, dm0=dm0, conv_tol=conv_tol, max_cycle=max_cycle, veff_fn=veff, verbose=verbose)
     r["nelec_grid"] = info.get("nelec")
-    r["ngrids"] = len(weights)
+    r["ngrids"] = info.get("ngrids", len(weights))
     return r
