@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--basis", default="cc-pVDZ")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-rooflines", action="store_true",
+                    help="skip the additional kernel-only legs (J-only variant; benzene/cc-pVTZ tensor) at N=1")
     ap.add_argument("--eig", default="sp2", choices=["sp2", "eigh"], help="projector method inside the SCF step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; 'gloo' only for rehearsing N>1 ranks on a 1-GPU box")
@@ -130,6 +132,31 @@ def main():
             "algorithmic_bytes": alg_bytes, "stored_bytes": stats["stored_bytes"],
             "stored_GBps": stats["stored_bytes"] / (ms * 1e-3) / 1e9}
 
+    # further kernel-only legs (N=1): the J-only variant (pure-functional RKS build) on this workload and both
+    # variants on the benzene/cc-pVTZ tensor (5.2 GB: beyond the 256 MiB Infinity Cache, the figure BASELINE's
+    # ">= 70 % of the HBM roofline on the J-build kernel" target is stated for)
+    more = []
+    if world == 1 and not args.no_extra_rooflines:
+        def leg(engine, nao, est, dm, label):
+            for wj, wk, name, nmat in ((True, False, "J only", 2), (True, True, "J+K", 3)):
+                if label.endswith(args.basis) and wk:
+                    continue  # already the headline roofline object
+                t = engine.time_jk_kernel(dm, reps=30, with_j=wj, with_k=wk)
+                b = 8.0 * est["n_unique_eri"] + 8.0 * nmat * nao * nao
+                more.append({"workload": label, "variant": name, "ms_per_launch": t, "algorithmic_bytes": b,
+                             "achieved": b / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, "stored_bytes": est["stored_bytes"]})
+        leg(mf.engine, n, stats, st["dm"], "benzene/" + args.basis)
+        if args.basis.lower() != "cc-pvtz":
+            from mi355scf.engine import Engine
+            mol3 = Mole(atom=BENZENE, basis="cc-pVTZ", verbose=0).build()
+            e3 = Engine(mol3)
+            st3 = e3.prepare_eri(1e-13)
+            g = torch.Generator(device="cpu").manual_seed(0)
+            a = torch.randn(mol3.nao, mol3.nao, generator=g, dtype=torch.float64)
+            leg(e3, mol3.nao, st3, (a + a.T).cuda(), "benzene/cc-pVTZ")
+            e3.close()
+
     if rank == 0:
         out = {"metric": "scf_iterations_per_sec", "value": args.steps / dt, "unit": "iter/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -137,7 +164,7 @@ def main():
                "config": {"workload": f"benzene RHF/{args.basis} SCF cycle (N_ao={n}, resident 8-fold ERI tiles)",
                           "n_ao": n, "n_unique_eri": stats["n_unique_eri"], "parallelism": f"tile-run shard x{world}",
                           "density_from_fock": args.eig},
-               "roofline": roof, "e_tot": st["e_tot"], "eri_seconds": stats["seconds_eri"], "setup_seconds": setup_s}
+               "roofline": roof, "roofline_more": more, "e_tot": st["e_tot"], "eri_seconds": stats["seconds_eri"], "setup_seconds": setup_s}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mol)
         print(json.dumps(out))

@@ -1495,9 +1495,9 @@ extern "C" int mi_build_jk(mi_ctx *c, const double *d_D, int n_dm, double *d_J, 
     return 0;
 }
 
-extern "C" int mi_time_jk_kernel(mi_ctx *c, const double *d_D, int reps, double *ms, void *stream)
+extern "C" int mi_time_jk_variant(mi_ctx *c, const double *d_D, int with_j, int with_k, int reps, double *ms, void *stream)
 {
-    if (!c || !d_D || !ms || reps < 1) return fail("mi_time_jk_kernel: bad argument");
+    if (!c || !d_D || !ms || reps < 1 || (!with_j && !with_k)) return fail("mi_time_jk_variant: bad argument");
     if (!c->eri_ready) return fail("mi_time_jk_kernel: call mi_eri_prepare first");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -1508,10 +1508,10 @@ extern "C" int mi_time_jk_kernel(mi_ctx *c, const double *d_D, int reps, double 
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    if (launch_jk(c, true, true, st)) return -1; // warm
+    if (launch_jk(c, with_j != 0, with_k != 0, st)) return -1; // warm
     HIPCHK(hipEventRecord(e0, st));
     for (int r = 0; r < reps; r++)
-        if (launch_jk(c, true, true, st)) return -1;
+        if (launch_jk(c, with_j != 0, with_k != 0, st)) return -1;
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipEventSynchronize(e1));
     float t = 0;
@@ -1520,6 +1520,11 @@ extern "C" int mi_time_jk_kernel(mi_ctx *c, const double *d_D, int reps, double 
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     return 0;
+}
+
+extern "C" int mi_time_jk_kernel(mi_ctx *c, const double *d_D, int reps, double *ms, void *stream)
+{
+    return mi_time_jk_variant(c, d_D, 1, 1, reps, ms, stream);
 }
 
 // =================================================================================================

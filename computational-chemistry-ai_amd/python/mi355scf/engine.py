@@ -57,6 +57,7 @@ def lib():
         L.mi_eri_get_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
         L.mi_build_jk.argtypes = [vp, vp, ctypes.c_int, vp, vp, vp]
         L.mi_time_jk_kernel.argtypes = [vp, vp, ctypes.c_int, dp, vp]
+        L.mi_time_jk_variant.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, vp]
         L.mi_diis_errvec.argtypes = [vp, vp, vp, vp]
         L.mi_diis_combine.argtypes = [vp, vp, dp, ctypes.c_int, vp, vp]
         L.mi_diis_dots.argtypes = [vp, vp, vp, ctypes.c_int, dp, vp]
@@ -195,11 +196,12 @@ class Engine:
             K = K[0] if with_k else None
         return J, K
 
-    def time_jk_kernel(self, dm, reps=20):
+    def time_jk_kernel(self, dm, reps=20, with_j=True, with_k=True):
         dm = torch.as_tensor(dm, dtype=torch.float64, device=self.device).contiguous()
         ms = ctypes.c_double()
         with torch.cuda.device(self.device):
-            _check(lib().mi_time_jk_kernel(self._h, dm.data_ptr(), reps, ctypes.byref(ms), self._stream()))
+            _check(lib().mi_time_jk_variant(self._h, dm.data_ptr(), int(with_j), int(with_k), reps, ctypes.byref(ms),
+                                            self._stream()))
         return ms.value
 
     # --- rows a7-a9 (DFT) ------------------------------------------------------------------------

@@ -89,6 +89,9 @@ int mi_build_jk(mi_ctx *ctx, const double *d_D, int n_dm, double *d_J, double *d
 /* Time `reps` back-to-back launches of the J/K digestion kernel alone with HIP events on `stream`
  * and return the average milliseconds per launch (bench.py's roofline leg). */
 int mi_time_jk_kernel(mi_ctx *ctx, const double *d_D, int reps, double *ms_per_launch, void *stream);
+/* Same measurement for the J-only (with_k = 0: the pure-functional RKS build) or K-only kernel variant. */
+int mi_time_jk_variant(mi_ctx *ctx, const double *d_D, int with_j, int with_k, int reps, double *ms_per_launch,
+                       void *stream);
 
 /* DIIS (Pulay) helpers on device: given F, D, S form e = S D F - F D S ... */
 /* err = A - A^T written in place of nothing: d_err[nao*nao] = d_SDF - d_SDF^T (fused epilogue). */

@@ -20,6 +20,10 @@ for basis in (sys.argv[1:] or ["cc-pVDZ", "cc-pVTZ"]):
     alg = 8.0 * st["n_unique_eri"] + 24.0 * n * n
     J, K = eng.get_jk(D)
     ms = min(eng.time_jk_kernel(D, reps=30) for _ in range(5))
+    ms_j = min(eng.time_jk_kernel(D, reps=30, with_k=False) for _ in range(5))
+    ms_k = min(eng.time_jk_kernel(D, reps=30, with_j=False) for _ in range(5))
+    alg_j = 8.0 * st["n_unique_eri"] + 16.0 * n * n
     print(json.dumps(dict(basis=basis, ms=round(ms, 4), alg_GBps=round(alg / ms / 1e6, 1), frac=round(alg / ms / 1e6 / 8000, 4),
-                          stored_GBps=round(st["stored_bytes"] / ms / 1e6, 1), Jsum=float(J.sum()), Ksum=float(K.sum()))), flush=True)
+                          stored_GBps=round(st["stored_bytes"] / ms / 1e6, 1),
+                          j_only_ms=round(ms_j, 4), j_only_frac=round(alg_j / ms_j / 1e6 / 8000, 4), k_only_ms=round(ms_k, 4), Jsum=float(J.sum()), Ksum=float(K.sum()))), flush=True)
     eng.close()
