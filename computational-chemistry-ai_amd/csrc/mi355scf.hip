@@ -1337,14 +1337,30 @@ __device__ inline double reduce8(const double v[8], int lane, int m2, int m1, in
     return red_select_xor(b[0], b[1], h0, m0);
 }
 
+// Read-only, wave-uniform operands (work-item records, tile directory, the J-L density rows) go through the
+// constant address space so that they are fetched with scalar loads into SGPRs instead of per-lane vector loads.
+#define MI_CONST_AS __attribute__((address_space(4)))
+template <class T> __device__ inline const MI_CONST_AS T *as_const(const T *p)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const MI_CONST_AS T *)p;
+#pragma clang diagnostic pop
+}
+
 template <bool WITH_J, bool WITH_K, bool NT>
 __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
 {
     const int lane = threadIdx.x;
     const int i = lane >> 3, k = lane & 7;
-    const int seg_end = A.wave_seg[blockIdx.x + 1];
-  for (int seg = A.wave_seg[blockIdx.x]; seg < seg_end; seg++) {
-    const RunRec R = A.runs[seg];
+    const MI_CONST_AS int *wave_seg = as_const(A.wave_seg);
+    const MI_CONST_AS int *tile_I = as_const(A.tile_I);
+    const MI_CONST_AS int64_t *tile_off = as_const(A.tile_off);
+    const MI_CONST_AS double *Du = as_const(A.D);
+    const int seg_end = wave_seg[blockIdx.x + 1];
+  for (int seg = wave_seg[blockIdx.x]; seg < seg_end; seg++) {
+    const MI_CONST_AS RunRec *rr = as_const(A.runs) + seg;
+    const RunRec R{rr->J, rr->K, rr->L, rr->first, rr->count};
     const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
     const int ld = A.ld;
     const int bj = BLK, bk = min(BLK, A.nao - K0); // tiles are padded to 8 j-rows
@@ -1364,12 +1380,17 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
         for (int l = 0; l < 8; l++) kjl[j][l] = 0.0;
     }
 
+    // the directory entry of tile t+1 is fetched while tile t is being digested
+    int I_next = tile_I[R.first];
+    int64_t off_next = tile_off[R.first];
     for (int t = 0; t < R.count; t++) {
         const int tid = R.first + t;
-        const int I0 = A.tile_I[tid] * BLK;
+        const int I0 = I_next * BLK;
+        const int64_t toff = off_next;
+        if (t + 1 < R.count) { I_next = tile_I[tid + 1]; off_next = tile_off[tid + 1]; }
         const int bi = min(BLK, A.nao - I0);
         const bool active = (i < bi) && (k < bk);
-        const d2_t *__restrict__ T = reinterpret_cast<const d2_t *>(A.tiles + A.tile_off[tid]) + (i * bk + k);
+        const d2_t *__restrict__ T = reinterpret_cast<const d2_t *>(A.tiles + toff) + (i * bk + k);
         const int cs = bi * bk; // double2 stride between (j,lp) chunks
         double dIJ[8], dIL[8];
 #pragma unroll
@@ -1390,7 +1411,7 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
                     if (active) x = NT ? __builtin_nontemporal_load(&T[(size_t)(j * 4 + lp) * cs]) : T[(size_t)(j * 4 + lp) * cs];
                     v[2 * lp] = x.x; v[2 * lp + 1] = x.y;
                 }
-                const double *__restrict__ dJL = D + (size_t)(J0 + j) * ld + L0; // wave-uniform row
+                const MI_CONST_AS double *dJL = Du + (size_t)(J0 + j) * ld + L0; // wave-uniform row (SGPRs)
 #pragma unroll
                 for (int l = 0; l < 8; l++) {
                     const double x = v[l];
