@@ -128,7 +128,8 @@ def main():
         traffic = None
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "ms_per_launch": ms,
-            "kernel": "jk_tiles_kernel<true,true,%s>" % ("true" if stats["stored_bytes"] > (256 << 20) else "false"),
+            "kernel": ("jk_tiles_kernel<true,true,true>" if stats["stored_bytes"] > (256 << 20)
+                       else "jk_tiles_pipe_kernel<true,false>"),
             "algorithmic_bytes": alg_bytes, "stored_bytes": stats["stored_bytes"],
             "stored_GBps": stats["stored_bytes"] / (ms * 1e-3) / 1e9}
 

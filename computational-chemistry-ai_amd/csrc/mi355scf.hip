@@ -252,6 +252,7 @@ struct mi_ctx {
     int opt_runmax = 0;      // tiles per J/K work item (0 = auto: ntiles/2048 clamped to [8,64])
     int opt_jk_waves = 0;    // 0: one wave per work item, longest first; >0: that many waves, equal-cost shares
     int opt_jk_nt = 1;       // nontemporal loads for the tile stream
+    int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
 };
 
 static inline int pc_index(int la, int lb) { return la * (la + 1) / 2 + lb; }
@@ -407,6 +408,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     if (k == "runmax") c->opt_runmax = (int)value;           // takes effect at the next mi_eri_prepare
     else if (k == "jk_waves") c->opt_jk_waves = (int)value; // takes effect at the next mi_eri_prepare
     else if (k == "jk_nt") c->opt_jk_nt = (int)value;
+    else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else return fail("mi_set_option: unknown key '%s'", key);
     return 0;
 }
@@ -1463,7 +1465,137 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
 }
 
 
+// Software-pipelined variant for the K-carrying builds (one wave per SIMD, so a wave has to overlap its own
+// loads with its own arithmetic): a tile is digested as two halves of 4 j-rows (16 double2 chunks per lane
+// each); while half A of tile t is being contracted, half B of tile t is in flight, and while half B is being
+// contracted, half A of tile t+1 is in flight.  Same register budget as holding one whole tile.
+template <bool NT>
+__device__ inline void jk_load_half(d2_t (&buf)[16], const d2_t *__restrict__ T, int cs, bool active, int half)
+{
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+            buf[c] = NT ? __builtin_nontemporal_load(&T[(size_t)(half * 16 + c) * cs]) : T[(size_t)(half * 16 + c) * cs];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; c++) buf[c] = d2_t{0.0, 0.0};
+    }
+}
 
+template <bool WITH_J, bool NT>
+__global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
+{
+    const int lane = threadIdx.x;
+    const int i = lane >> 3, k = lane & 7;
+    const MI_CONST_AS int *wave_seg = as_const(A.wave_seg);
+    const MI_CONST_AS int *tile_I = as_const(A.tile_I);
+    const MI_CONST_AS int64_t *tile_off = as_const(A.tile_off);
+    const MI_CONST_AS double *Du = as_const(A.D);
+    const int seg_end = wave_seg[blockIdx.x + 1];
+  for (int seg = wave_seg[blockIdx.x]; seg < seg_end; seg++) {
+    const MI_CONST_AS RunRec *rr = as_const(A.runs) + seg;
+    const RunRec R{rr->J, rr->K, rr->L, rr->first, rr->count};
+    const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
+    const int ld = A.ld;
+    const int bk = min(BLK, A.nao - K0);
+    const double *__restrict__ D = A.D;
+
+    double dKL[8], dJK[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) dKL[l] = D[(size_t)(K0 + k) * ld + L0 + l];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dJK[j] = D[(size_t)(J0 + j) * ld + K0 + k];
+    double kjl[8][8], jkl[8], kjk[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        jkl[j] = 0.0; kjk[j] = 0.0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) kjl[j][l] = 0.0;
+    }
+
+    d2_t bufA[16], bufB[16];
+    int I_cur = tile_I[R.first];
+    int64_t off_cur = tile_off[R.first];
+    {
+        const int bi0 = min(BLK, A.nao - I_cur * BLK);
+        jk_load_half<NT>(bufA, reinterpret_cast<const d2_t *>(A.tiles + off_cur) + (i * bk + k), bi0 * bk, (i < bi0) && (k < bk), 0);
+    }
+    for (int t = 0; t < R.count; t++) {
+        const int tid = R.first + t;
+        const int I0 = I_cur * BLK;
+        const int bi = min(BLK, A.nao - I0);
+        const bool active = (i < bi) && (k < bk);
+        const bool more = t + 1 < R.count;
+        int I_nx = I_cur;
+        int64_t off_nx = off_cur;
+        if (more) { I_nx = tile_I[tid + 1]; off_nx = tile_off[tid + 1]; }
+        double dIJ[8], dIL[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) dIJ[j] = D[(size_t)(I0 + i) * ld + J0 + j];
+#pragma unroll
+        for (int l = 0; l < 8; l++) dIL[l] = D[(size_t)(I0 + i) * ld + L0 + l];
+        const double dIK = D[(size_t)(I0 + i) * ld + K0 + k];
+        jk_load_half<NT>(bufB, reinterpret_cast<const d2_t *>(A.tiles + off_cur) + (i * bk + k), bi * bk, active, 1);
+
+        double kik = 0.0, jij[8], kil[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { jij[j] = 0.0; kil[j] = 0.0; }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            d2_t (&buf)[16] = half ? bufB : bufA;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = half * 4 + jj;
+                const MI_CONST_AS double *dJL = Du + (size_t)(J0 + j) * ld + L0;
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    const double x = (l & 1) ? buf[jj * 4 + (l >> 1)].y : buf[jj * 4 + (l >> 1)].x;
+                    kik = fma(x, dJL[l], kik);
+                    kil[l] = fma(x, dJK[j], kil[l]);
+                    kjl[j][l] = fma(x, dIK, kjl[j][l]);
+                    kjk[j] = fma(x, dIL[l], kjk[j]);
+                    if (WITH_J) {
+                        jij[j] = fma(x, dKL[l], jij[j]);
+                        jkl[l] = fma(x, dIJ[j], jkl[l]);
+                    }
+                }
+            }
+            if (half == 0 && more) {
+                const int bin = min(BLK, A.nao - I_nx * BLK);
+                jk_load_half<NT>(bufA, reinterpret_cast<const d2_t *>(A.tiles + off_nx) + (i * bk + k), bin * bk, (i < bin) && (k < bk), 0);
+            }
+        }
+        atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik);
+        {
+            double r = reduce8(kil, lane, 4, 2, 1);
+            atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + L0 + k], r);
+        }
+        if (WITH_J) {
+            double r = reduce8(jij, lane, 4, 2, 1);
+            atomicAdd(&A.Jacc[(size_t)(I0 + i) * ld + J0 + k], r);
+        }
+        I_cur = I_nx; off_cur = off_nx;
+    }
+    if (WITH_J) {
+        double r = reduce8(jkl, lane, 32, 16, 8);
+        atomicAdd(&A.Jacc[(size_t)(K0 + k) * ld + L0 + i], r);
+    }
+    {
+        double r = reduce8(kjk, lane, 32, 16, 8);
+        atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + K0 + k], r);
+        double s8[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            double col[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) col[j] = kjl[j][l];
+            s8[l] = reduce8(col, lane, 32, 16, 8);
+        }
+        double r2 = reduce8(s8, lane, 4, 2, 1);
+        atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + L0 + k], r2);
+    }
+  }
+}
 
 __global__ void pad_density_kernel(const double *D, double *Dp, int nao, int ld)
 {
@@ -1489,7 +1621,12 @@ static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
     dim3 g(A.nruns), b(64);
     // nontemporal loads only when the tensor cannot stay in the 256 MiB Infinity Cache between SCF cycles
     const bool nt = c->opt_jk_nt != 0 && (c->opt_jk_nt > 1 || c->tile_doubles * 8 > ((int64_t)256 << 20));
-    if (wj && wk) { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<true, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<true, true, false>), g, b, 0, st, A); }
+    const bool pipe = c->opt_jk_pipe > 0 || (c->opt_jk_pipe < 0 && c->tile_doubles * 8 <= ((int64_t)256 << 20));
+    if (pipe && wk) {
+        if (wj) { if (nt) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, false>), g, b, 0, st, A); }
+        else hipLaunchKernelGGL((jk_tiles_pipe_kernel<false, true>), g, b, 0, st, A);
+    }
+    else if (wj && wk) { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<true, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<true, true, false>), g, b, 0, st, A); }
     else if (wj) hipLaunchKernelGGL((jk_tiles_kernel<true, false, true>), g, b, 0, st, A);
     else hipLaunchKernelGGL((jk_tiles_kernel<false, true, true>), g, b, 0, st, A);
     HIPCHK(hipGetLastError());
