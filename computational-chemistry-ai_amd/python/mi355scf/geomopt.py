@@ -5,14 +5,17 @@ geomeTRIC (pinned 1.1 in the reference image, `.devcontainer/Dockerfile:120`) is
 independent quasi-Newton optimiser with geomeTRIC's DEFAULT convergence set [MEM]: |dE| < 1e-6 Ha,
 RMS/max gradient < 3e-4 / 4.5e-4 Ha/Bohr, RMS/max displacement < 1.2e-3 / 1.8e-3 Angstrom.  Step-for-step
 parity with geomeTRIC is impossible; only the converged geometry/energy within those thresholds is comparable.
-BFGS in Cartesian coordinates, trust-radius limited; the initial Hessian is a valence-force-field model
-(stretches 0.5, bends 0.2, torsions 0.1 a.u. on the detected bond graph, B^T K B) so that floppy molecules
-converge in tens of steps.  Returns a `Mole` at the optimised geometry, like the PySCF wrapper.
+Default: BFGS in redundant primitive internal coordinates (`internals.py`: stretches, bends, torsions on the
+detected bond graph; diagonal 0.5/0.2/0.1 a.u. Hessian guess; trust-radius restricted steps; iterative
+back-transformation).  Fallback (linear bends, rank-deficient primitive sets): BFGS in Cartesian coordinates
+on the valence-force-field model Hessian B^T K B.  Returns a `Mole` at the optimised geometry, like the PySCF
+wrapper.
 """
 import itertools
 
 import numpy as np
 
+from .internals import Internals
 from .mole import BOHR
 
 CONV = dict(energy=1e-6, grms=3e-4, gmax=4.5e-4, drms=1.2e-3, dmax=1.8e-3)
@@ -72,28 +75,58 @@ def model_hessian(mol, x):
     return H
 
 
-def optimize(mf, maxsteps=100, callback=None, **kw):
-    gs = mf.nuc_grad_method().as_scanner()
-    mol = mf.mol
+def _report(e_new, de, g_new, dx):
+    disp = dx.reshape(-1, 3) * BOHR
+    d_rms = np.sqrt((disp ** 2).sum(axis=1).mean())
+    d_max = np.sqrt((disp ** 2).sum(axis=1)).max()
+    gm = g_new.reshape(-1, 3)
+    g_rms = np.sqrt((gm ** 2).sum(axis=1).mean())
+    g_max = np.sqrt((gm ** 2).sum(axis=1)).max()
+    done = (abs(de) < CONV["energy"] and g_rms < CONV["grms"] and g_max < CONV["gmax"]
+            and d_rms < CONV["drms"] and d_max < CONV["dmax"])
+    return done, f"{e_new:16.10f}  {de:+.2e}  {g_rms:.3e}  {g_max:.3e}  {d_rms:.3e}  {d_max:.3e}"
+
+
+def _bfgs(H, s, y):
+    sy = s @ y
+    if sy > 1e-10:
+        Hs = H @ s
+        H = H + np.outer(y, y) / sy - np.outer(Hs, Hs) / (s @ Hs)
+    return H
+
+
+def _restricted_step(H, g, trust):
+    """Minimiser of the quadratic model inside |s| <= trust (level-shifted Newton step; H is made positive)."""
+    w, v = np.linalg.eigh(H)
+    gv = v.T @ g
+    w = np.maximum(np.abs(w), 1e-4)
+    s = -(v * (1.0 / w)) @ gv
+    if np.linalg.norm(s) <= trust:
+        return s
+    lo, hi = 0.0, 1e3
+    for _ in range(100):  # bisection on the shift: |s(mu)| decreases monotonically
+        mu = 0.5 * (lo + hi)
+        if np.linalg.norm(gv / (w + mu)) > trust:
+            lo = mu
+        else:
+            hi = mu
+    return -(v * (1.0 / (w + hi))) @ gv
+
+
+def optimize_cartesian(energy_grad, mol, maxsteps=100, log=lambda m: None, callback=None):
+    """BFGS in Cartesian coordinates on a valence-force-field model Hessian (fallback for molecules whose
+    primitive set is incomplete, e.g. with linear bends)."""
     x = mol.atom_coords().ravel().copy()
-    n = x.size
     H = model_hessian(mol, x.reshape(-1, 3))
     trust = 0.3
-    e, g = gs(mol)
+    e, g = energy_grad(mol)
     g = g.ravel()
-    log = lambda msg: mf._log(3, msg)
-    log("Step    Energy (Ha)        dE         RMS grad    max grad    RMS disp(A)  max disp(A)")
     converged = False
     for step in range(1, maxsteps + 1):
-        w, v = np.linalg.eigh(H)
-        w = np.maximum(np.abs(w), 1e-3)
-        dx = -(v * (1.0 / w)) @ (v.T @ g)
+        dx = _restricted_step(H, g, trust)
         nrm = np.linalg.norm(dx)
-        if nrm > trust:
-            dx *= trust / nrm
-        x_new = x + dx
-        mol_new = mol.set_geom_(x_new.reshape(-1, 3), unit="Bohr", inplace=False)
-        e_new, g_new = gs(mol_new)
+        mol_new = mol.set_geom_((x + dx).reshape(-1, 3), unit="Bohr", inplace=False)
+        e_new, g_new = energy_grad(mol_new)
         g_new = g_new.ravel()
         de = e_new - e
         pred = g @ dx + 0.5 * dx @ H @ dx
@@ -106,28 +139,91 @@ def optimize(mf, maxsteps=100, callback=None, **kw):
             trust = min(trust * 1.5, 0.5)
         elif ratio < 0.25:
             trust = max(trust * 0.5, 0.02)
-        s, y = dx, g_new - g
-        sy = s @ y
-        if sy > 1e-10:
-            Hs = H @ s
-            H = H + np.outer(y, y) / sy - np.outer(Hs, Hs) / (s @ Hs)
-        disp = dx.reshape(-1, 3) * BOHR
-        d_rms = np.sqrt((disp ** 2).sum(axis=1).mean())
-        d_max = np.sqrt((disp ** 2).sum(axis=1)).max()
-        gm = g_new.reshape(-1, 3)
-        g_rms = np.sqrt((gm ** 2).sum(axis=1).mean())
-        g_max = np.sqrt((gm ** 2).sum(axis=1)).max()
-        log(f"{step:4d}  {e_new:16.10f}  {de:+.2e}  {g_rms:.3e}  {g_max:.3e}  {d_rms:.3e}  {d_max:.3e}")
-        x, e, g, mol = x_new, e_new, g_new, mol_new
+        H = _bfgs(H, dx, g_new - g)
+        done, line = _report(e_new, de, g_new, dx)
+        log(f"{step:4d}  {line}")
+        x, e, g, mol = x + dx, e_new, g_new, mol_new
         if callback is not None:
             callback(locals())
-        if (abs(de) < CONV["energy"] and g_rms < CONV["grms"] and g_max < CONV["gmax"]
-                and d_rms < CONV["drms"] and d_max < CONV["dmax"]):
+        if done:
             converged = True
             break
+    return mol, converged, step
+
+
+def optimize_internal(energy_grad, mol, maxsteps=100, log=lambda m: None, callback=None):
+    """BFGS in redundant primitive internal coordinates (stretches, bends, torsions).
+
+    Per step: g_q = G^- B g_x; Newton step on the projected Hessian P H P + 1000 (1 - P) restricted to the
+    trust radius; iterative back-transformation to Cartesians; BFGS update with the ACHIEVED internal step.
+    Returns (mol, converged, steps) or None when the primitive set cannot span the 3N-6 internal motions."""
+    x = mol.atom_coords().copy()
+    n = len(x)
+    ic = Internals(mol.atom_charges(), x)
+    B = ic.bmatrix(x)
+    Ginv, P, rank = ic.ginv(B)
+    if n < 2 or ic.has_linear or rank < max(3 * n - 6, 1):
+        return None
+    H = np.diag(ic.guess_hessian_diag())
+    trust = 0.3
+    e, g = energy_grad(mol)
+    gq = Ginv @ (B @ g.ravel())
+    converged = False
+    for step in range(1, maxsteps + 1):
+        Hp = P @ H @ P + 1000.0 * (np.eye(ic.nq) - P)
+        dq = _restricted_step(Hp, P @ gq, trust)
+        x_new, dq_got = ic.to_cartesian(x, dq)
+        dx = (x_new - x).ravel()
+        mol_new = mol.set_geom_(x_new, unit="Bohr", inplace=False)
+        e_new, g_new = energy_grad(mol_new)
+        de = e_new - e
+        pred = gq @ dq_got + 0.5 * dq_got @ H @ dq_got
+        ratio = de / pred if abs(pred) > 1e-14 else 1.0
+        if de > 1e-5 and trust > 0.01:
+            trust *= 0.5
+            log(f"{step:4d}  step rejected (dE = {de:+.2e}); trust radius -> {trust:.3f}")
+            continue
+        nrm = np.linalg.norm(dq_got)
+        if ratio > 0.75 and nrm > 0.8 * trust:
+            trust = min(trust * 1.5, 0.5)
+        elif ratio < 0.25:
+            trust = max(trust * 0.5, 0.02)
+        B_new = ic.bmatrix(x_new)
+        Ginv_new, P_new, rank_new = ic.ginv(B_new)
+        gq_new = Ginv_new @ (B_new @ g_new.ravel())
+        H = _bfgs(H, dq_got, gq_new - gq)
+        done, line = _report(e_new, de, g_new.ravel(), dx)
+        log(f"{step:4d}  {line}")
+        x, e, g, gq, mol, B, Ginv, P = x_new, e_new, g_new, gq_new, mol_new, B_new, Ginv_new, P_new
+        if callback is not None:
+            callback(locals())
+        if done:
+            converged = True
+            break
+        if rank_new < 3 * n - 6:   # a bend went linear / the primitive set lost rank: finish in Cartesians
+            log("      primitive internal coordinates lost rank; continuing in Cartesian coordinates")
+            mol2, conv2, st2 = optimize_cartesian(energy_grad, mol, maxsteps - step, log, callback)
+            return mol2, conv2, step + st2
+    return mol, converged, step
+
+
+def optimize(mf, maxsteps=100, callback=None, coordsys="internal", **kw):
+    """Drop-in for `pyscf.geomopt.geometric_solver.optimize(mf, maxsteps=...)`: returns a `Mole` at the
+    optimised geometry.  `coordsys="internal"` (default; redundant primitive internals, Cartesian fallback) or
+    "cart"."""
+    gs = mf.nuc_grad_method().as_scanner()
+    mol = mf.mol
+    log = lambda msg: mf._log(3, msg)
+    log("Step    Energy (Ha)        dE         RMS grad    max grad    RMS disp(A)  max disp(A)")
+    res = None
+    if coordsys.lower() in ("internal", "ric", "tric", "prim", "dlc"):
+        res = optimize_internal(gs, mol, maxsteps, log, callback)
+    if res is None:
+        res = optimize_cartesian(gs, mol, maxsteps, log, callback)
+    mol_opt, converged, step = res
     log("Geometry optimization " + (f"converged in {step} steps" if converged else f"NOT converged in {maxsteps} steps"))
-    mol.verbose = mf.mol.verbose
-    return mol
+    mol_opt.verbose = mf.mol.verbose
+    return mol_opt
 
 
 kernel = optimize
