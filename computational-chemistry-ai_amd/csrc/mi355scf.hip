@@ -252,6 +252,7 @@ struct mi_ctx {
     int opt_runmax = 0;      // tiles per J/K work item (0 = auto: ntiles/2048 clamped to [8,64])
     int opt_jk_waves = 0;    // 0: one wave per work item, longest first; >0: that many waves, equal-cost shares
     int opt_jk_nt = 1;       // nontemporal loads for the tile stream
+    double opt_grad_dtol = 1e-13; // gradient: skip quartets with q_ab q_cd max|G| below this (0: Schwarz only)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
 };
 
@@ -409,6 +410,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_waves") c->opt_jk_waves = (int)value; // takes effect at the next mi_eri_prepare
     else if (k == "jk_nt") c->opt_jk_nt = (int)value;
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
+    else if (k == "grad_dtol") c->opt_grad_dtol = value;
     else return fail("mi_set_option: unknown key '%s'", key);
     return 0;
 }
@@ -598,7 +600,19 @@ struct EriArgs {
     int swap;                // 1: the task's (bra index, ket index) address (ket[], bra[]) instead
     const int32_t *own_table; // non-null on a sharded context: skip quartets none of whose tiles live on this rank
     int ni, nj, nk, nl;       // spherical shell sizes (for the ownership test)
+    // gradient only: density-weighted Schwarz screening  q_ab q_cd max|G| < dtol  (dmax == nullptr: off)
+    const double *q_bra, *q_ket, *dmax; // Schwarz factors of the two pair lists; max |D| per shell pair [nbas][nbas]
+    int nbas_d;
+    double dtol, hyb;
 };
+
+// Upper bound of |G| = |D_ab D_cd - hyb/4 (D_ac D_bd + D_ad D_bc)| over the AO quadruples of a shell quartet.
+__device__ inline double quartet_density_bound(const double *dmax, int nb, int a, int b, int c, int d, double hyb)
+{
+    double coul = dmax[a * nb + b] * dmax[c * nb + d];
+    double exch = dmax[a * nb + c] * dmax[b * nb + d] + dmax[a * nb + d] * dmax[b * nb + c];
+    return coul + 0.25 * hyb * exch;
+}
 
 __device__ inline void find_task(const int64_t *prefix, int nbra, int64_t t, int &ib, int &ik)
 {
@@ -643,6 +657,7 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
     if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
     if (A.own_table && !quartet_has_resident_tile(A.own_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane)) return;
+    if (A.dmax && A.q_bra[ib] * A.q_ket[ik] * quartet_density_bound(A.dmax, A.nbas_d, ab.sh_i, ab.sh_j, cd.sh_i, cd.sh_j, A.hyb) < A.dtol) return;
     const int n = A.nroots, tsz = A.tsz, M1 = A.mmax + 1;
     const int ncd = cd.nprim, nPQ = ab.nprim * ncd;
     const int PB = A.PB;
@@ -1079,6 +1094,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         P.recs.swap(r2);
         P.q.swap(q2);
         if (upload(&P.d_recs, P.recs)) return -1;
+        if (upload(&P.d_q, P.q)) return -1; // Schwarz factors in the sorted order (density-weighted screening of the gradient)
     }
 
     lap("sort pairs");
@@ -2530,6 +2546,9 @@ struct GradXfArgs {
     int inv_from_second; // translational invariance: 1: the skipped shell is dp.sh_j, 0: it is cd.sh_i
     int natm3;           // grad points to GRAD_COPIES private copies of [natm*3] (atomic contention relief)
     int64_t nbatch;      // tasks in this launch
+    const double *q_bra, *q_ket, *dmax; // same screening as EriArgs (the Rys kernel left these quartets' blocks unwritten)
+    int nbas_d;
+    double dtol;
 };
 #define GRAD_COPIES 4096
 
@@ -2543,7 +2562,7 @@ __global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
     constexpr int QPW = 64 / GSZ;
     const int grp = threadIdx.x / GSZ, lane = threadIdx.x % GSZ;
     const int64_t tl = (int64_t)blockIdx.x * QPW + grp; // task index inside this batch
-    const bool live = tl < A.nbatch;
+    const bool in_batch = tl < A.nbatch;
     const bool has_m = A.dminus != nullptr && A.ne_m > 0;
     const int nsab = A.ns1 * A.ns2, nf = A.nf;
     const size_t region = (size_t)A.ne_p * nf + (has_m ? (size_t)A.ne_m * nf : 0) + (size_t)nsab * A.nscd + (size_t)nsab * nf;
@@ -2553,10 +2572,12 @@ __global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
     double *G = E0m + (has_m ? (size_t)A.ne_m * nf : 0);      // [nsab][nscd]
     double *Y = G + (size_t)nsab * A.nscd;                    // [nsab][nf]
     int ib = 0, ik = 0;
-    if (live) find_task(A.prefix, A.nbra, A.t0 + tl, ib, ik);
+    if (in_batch) find_task(A.prefix, A.nbra, A.t0 + tl, ib, ik);
     const bool same_pair = A.same_class && ib == ik;
     if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec dp = A.dplus[ib], cd = A.ket[ik];
+    const bool live = in_batch && !(A.dmax && A.q_bra[ib] * A.q_ket[ik] *
+                                    quartet_density_bound(A.dmax, A.nbas_d, dp.sh_i, dp.sh_j, cd.sh_i, cd.sh_j, A.hyb) < A.dtol);
     int m_off_m = 0;
     const double *D = A.D;
     const int ld = A.ld;
@@ -2624,6 +2645,18 @@ __global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
     }
 }
 
+// max |D| over the AO block of every shell pair (density-weighted screening of the derivative quartets)
+__global__ void shell_dmax_kernel(const double *D, int ld, const int *sh_ao, const int *sh_n, int nbas, double *out)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nbas * nbas) return;
+    int a = idx / nbas, b = idx - a * nbas;
+    double m = 0.0;
+    for (int i = 0; i < sh_n[a]; i++)
+        for (int j = 0; j < sh_n[b]; j++) m = fmax(m, fabs(D[(size_t)(sh_ao[a] + i) * ld + sh_ao[b] + j]));
+    out[idx] = m;
+}
+
 __global__ void grad_reduce_copies_kernel(const double *copies, int natm3, double *grad)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2648,6 +2681,18 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
     for (int i = 0; i < c->nbas; i++) shell_atom[i] = c->shells[i].atom;
     int *d_shell_atom = nullptr;
     if (upload(&d_shell_atom, shell_atom)) return -1;
+    // density-weighted screening: q_ab q_cd max|G| < grad_dtol skips the quartet (0 disables)
+    double *d_dmax = nullptr;
+    int *d_sh_ao = nullptr, *d_sh_n = nullptr;
+    if (c->opt_grad_dtol > 0.0) {
+        std::vector<int> sh_ao(c->nbas), sh_n(c->nbas);
+        for (int i = 0; i < c->nbas; i++) { sh_ao[i] = c->shells[i].ao; sh_n[i] = 2 * c->shells[i].l + 1; }
+        if (upload(&d_sh_ao, sh_ao) || upload(&d_sh_n, sh_n)) return -1;
+        HIPCHK(hipMalloc(&d_dmax, sizeof(double) * (size_t)c->nbas * c->nbas));
+        hipLaunchKernelGGL(shell_dmax_kernel, dim3((c->nbas * c->nbas + 255) / 256), dim3(256), 0, st, c->d_Dpad, c->ldp, d_sh_ao, d_sh_n,
+                           c->nbas, d_dmax);
+        HIPCHK(hipGetLastError());
+    }
     const int natm3 = c->natm * 3;
     double *d_gcopies = nullptr;
     HIPCHK(hipMalloc(&d_gcopies, sizeof(double) * (size_t)GRAD_COPIES * natm3));
@@ -2713,7 +2758,10 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                     Em.bra = Dc.d_g_recs[orient][1]; Em.ket = Oc.d_recs; Em.prim = c->d_prim; Em.prefix = d_prefix; Em.nbra = Ep.nbra;
                     Em.comp = d_comp_m; Em.work = d_wm; Em.rys = c->rys; Em.diag = 0; Em.swap = Ep.swap;
                 }
+                Ep.q_bra = Dc.d_q; Ep.q_ket = Oc.d_q; Ep.dmax = d_dmax; Ep.nbas_d = c->nbas; Ep.dtol = c->opt_grad_dtol; Ep.hyb = hyb;
+                if (has_m) { Em.q_bra = Ep.q_bra; Em.q_ket = Ep.q_ket; Em.dmax = d_dmax; Em.nbas_d = c->nbas; Em.dtol = Ep.dtol; Em.hyb = hyb; }
                 GradXfArgs X{};
+                X.q_bra = Ep.q_bra; X.q_ket = Ep.q_ket; X.dmax = d_dmax; X.nbas_d = c->nbas; X.dtol = Ep.dtol;
                 X.dplus = Dc.d_g_recs[orient][0]; X.dminus = has_m ? Dc.d_g_recs[orient][1] : nullptr; X.ket = Oc.d_recs;
                 X.Mbuf = c->d_M; X.prefix = d_prefix; X.nbra = Ep.nbra; X.swap = Ep.swap; X.same_class = (bc == kc);
                 X.ne_p = ne_of(l1 + 1, l2); X.ne_m = has_m ? ne_of(l1 - 1, l2) : 0; X.nf = Oc.ne;
@@ -2761,6 +2809,9 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count());
     if (d_prefix) hipFree(d_prefix);
     hipFree(d_wp); hipFree(d_wm); hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_shell_atom);
+    if (d_dmax) hipFree(d_dmax);
+    if (d_sh_ao) hipFree(d_sh_ao);
+    if (d_sh_n) hipFree(d_sh_n);
     return 0;
 }
 
