@@ -614,9 +614,14 @@ __device__ inline double quartet_density_bound(const double *dmax, int nb, int a
     return coul + 0.25 * hyb * exch;
 }
 
+// Task t of a class pair -> (bra pair index, ket index).  `prefix` holds the nbra+1 cumulative task counts followed by
+// a coarse index (one entry per 1024 tasks: the bra index of task g*1024, see append_coarse_index), so the search
+// touches two neighbouring coarse entries and then only the few prefix entries between them.
 __device__ inline void find_task(const int64_t *prefix, int nbra, int64_t t, int &ib, int &ik)
 {
-    int lo = 0, hi = nbra; // find ib with prefix[ib] <= t < prefix[ib+1]
+    const int64_t *coarse = prefix + nbra + 1;
+    const int64_t g = t >> 10;
+    int lo = (int)coarse[g], hi = min((int)coarse[g + 1] + 1, nbra); // prefix[lo] <= t < prefix[hi]
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (prefix[mid] <= t) lo = mid; else hi = mid;
@@ -743,6 +748,35 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
     }
 }
 
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// One 16x16 tile of C = A B on a single wave with v_mfma_f64_16x16x4_f64 (used by the per-quartet transformation
+// kernels, whose matrices are a few tens of rows/columns: one operand load per 16 FMAs instead of two per FMA).
+//   A(m,k) = A[m*sam + k*sak] for m < M, B(k,n) = B[k*sbk + n*sbn] for n < N, k < K; out-of-range elements read as 0.
+// Result layout: element r of the return value is C[m0 + (lane>>4) + 4r][n0 + (lane&15)].
+__device__ inline d4_t wave_mfma_tile(const double *A, int sam, int sak, int M, const double *B, int sbk, int sbn, int N, int K, int m0,
+                                      int n0, int lane)
+{
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    const int m = m0 + (lane & 15), n = n0 + (lane & 15), kq = lane >> 4;
+    const bool mv = m < M, nv = n < N;
+    const double *pa = A + (size_t)(mv ? m : 0) * sam, *pb = B + (size_t)(nv ? n : 0) * sbn;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kq;
+        const bool kv = k < K;
+        const double a = (mv && kv) ? pa[(size_t)k * sak] : 0.0;
+        const double b = (nv && kv) ? pb[(size_t)k * sbk] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// MFMA pays when the zero padding of the 16x16x4 tiles wastes less than ~3/4 of the instruction
+__device__ __host__ inline bool mfma_worthwhile(int M, int N, int K)
+{
+    const int pm = (M + 15) / 16 * 16, pn = (N + 15) / 16 * 16, pk = (K + 3) / 4 * 4;
+    return 4 * M * N * K >= pm * pn * pk;
+}
+
 // =================================================================================================
 // ERI generation, kernel 2: out[ab][cd] = M_ab . E0 . M_cd^T (HRR + cart->sph folded into M), then
 // scatter every symmetry image that lands in a canonical resident tile.  One wave per quartet.
@@ -781,10 +815,15 @@ __device__ inline void put_tile(const XfArgs &A, int i, int j, int k, int l, dou
     A.tiles[A.tile_off[t] + ((size_t)((jj * 4 + (ll >> 1)) * (bi * bk) + ii * bk + kk) * 2 + (ll & 1))] = w;
 }
 
+// MFMA = true: instantiation with the matrix-core paths for the large angular classes; MFMA = false: lean kernel for
+// the small classes that make up most quartets.  One wave per quartet in both (four waves sharing a quartet's LDS
+// blocks were measured slower: 0.50 vs 0.46 s for ibuprofen/def2-TZVP).
+template <bool MFMA>
 __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
 {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    constexpr int NT = 64, NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ib, ik;
     find_task(A.prefix, A.nbra, A.t0 + blockIdx.x, ib, ik);
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
@@ -792,7 +831,7 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
     const double *E0g = A.work + (size_t)blockIdx.x * A.ncomp;
     double *E0 = lds;                 // [ne][nf]
     double *X = lds + A.ne * A.nf;    // [nsab][nf]
-    for (int c = lane; c < A.ne * A.nf; c += 64) E0[c] = E0g[c];
+    for (int c = tid; c < A.ne * A.nf; c += NT) E0[c] = E0g[c];
     __syncthreads();
     const double *Mab = A.Mbuf + ab.m_off, *Mcd = A.Mbuf + cd.m_off;
     // which of the 8 index images can land in a canonical tile (I >= J, K >= L) at all: decided once per quartet
@@ -806,17 +845,7 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
         mask = (ok(0, 1, 2, 3) ? 1u : 0u) | (ok(1, 0, 2, 3) ? 2u : 0u) | (ok(0, 1, 3, 2) ? 4u : 0u) | (ok(1, 0, 3, 2) ? 8u : 0u) |
                (ok(2, 3, 0, 1) ? 16u : 0u) | (ok(3, 2, 0, 1) ? 32u : 0u) | (ok(2, 3, 1, 0) ? 64u : 0u) | (ok(3, 2, 1, 0) ? 128u : 0u);
     }
-    for (int o = lane; o < A.nsab * A.nf; o += 64) {
-        int r = o / A.nf, f = o - r * A.nf;
-        double s = 0.0;
-        for (int e = 0; e < A.ne; e++) s += Mab[r * A.ne + e] * E0[e * A.nf + f];
-        X[o] = s;
-    }
-    __syncthreads();
-    for (int o = lane; o < A.nsab * A.nscd; o += 64) {
-        int r = o / A.nscd, c = o - r * A.nscd;
-        double s = 0.0;
-        for (int f = 0; f < A.nf; f++) s += X[r * A.nf + f] * Mcd[c * A.nf + f];
+    auto emit = [&](int r, int c, double s) {
         int sa = r / A.nsb, sb = r - sa * A.nsb, sc = c / A.nsd, sd = c - sc * A.nsd;
         int i = ab.ao_i + sa, j = ab.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
         if (mask & 1) put_tile(A, i, j, k, l, s);
@@ -827,6 +856,48 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
         if (mask & 32) put_tile(A, l, k, i, j, s);
         if (mask & 64) put_tile(A, k, l, j, i, s);
         if (mask & 128) put_tile(A, l, k, j, i, s);
+    };
+    // X = Mab E0, out = X Mcd^T: FP64 MFMA tiles for the large angular classes, per-lane dot products otherwise
+    if (MFMA && mfma_worthwhile(A.nsab, A.nf, A.ne)) {
+        int tile = 0;
+        for (int m0 = 0; m0 < A.nsab; m0 += 16)
+            for (int n0 = 0; n0 < A.nf; n0 += 16) {
+                if ((tile++) % NW != wave) continue;
+                d4_t x = wave_mfma_tile(Mab, A.ne, 1, A.nsab, E0, A.nf, 1, A.nf, A.ne, m0, n0, lane);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int r = m0 + (lane >> 4) + 4 * q, f = n0 + (lane & 15);
+                    if (r < A.nsab && f < A.nf) X[r * A.nf + f] = x[q];
+                }
+            }
+    } else {
+        for (int o = tid; o < A.nsab * A.nf; o += NT) {
+            int r = o / A.nf, f = o - r * A.nf;
+            double s = 0.0;
+            for (int e = 0; e < A.ne; e++) s += Mab[r * A.ne + e] * E0[e * A.nf + f];
+            X[o] = s;
+        }
+    }
+    __syncthreads();
+    if (MFMA && mfma_worthwhile(A.nsab, A.nscd, A.nf)) {
+        int tile = 0;
+        for (int m0 = 0; m0 < A.nsab; m0 += 16)
+            for (int n0 = 0; n0 < A.nscd; n0 += 16) {
+                if ((tile++) % NW != wave) continue;
+                d4_t o4 = wave_mfma_tile(X, A.nf, 1, A.nsab, Mcd, 1, A.nf, A.nscd, A.nf, m0, n0, lane);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int r = m0 + (lane >> 4) + 4 * q, c = n0 + (lane & 15);
+                    if (r < A.nsab && c < A.nscd) emit(r, c, o4[q]);
+                }
+            }
+    } else {
+        for (int o = tid; o < A.nsab * A.nscd; o += NT) {
+            int r = o / A.nscd, c = o - r * A.nscd;
+            double s = 0.0;
+            for (int f = 0; f < A.nf; f++) s += X[r * A.nf + f] * Mcd[c * A.nf + f];
+            emit(r, c, s);
+        }
     }
 }
 
@@ -919,6 +990,21 @@ static void build_M(int la, int lb, const double AB[3], const std::vector<double
                             }
                 }
         }
+}
+
+// coarse[g] = largest bra index ib with prefix[ib] <= g*1024, for g = 0 .. ntask/1024 + 1 (appended to `prefix`)
+static void append_coarse_index(std::vector<int64_t> &prefix)
+{
+    const int nbra = (int)prefix.size() - 1;
+    const int64_t ntask = prefix.back();
+    const int64_t ng = (ntask >> 10) + 2;
+    prefix.reserve(prefix.size() + (size_t)ng);
+    int ib = 0;
+    for (int64_t g = 0; g < ng; g++) {
+        const int64_t t = g << 10;
+        while (ib < nbra && prefix[ib + 1] <= t) ib++;
+        prefix.push_back(ib);
+    }
 }
 
 template <class T>
@@ -1253,6 +1339,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                 prefix[b + 1] = prefix[b] + cnt;
             }
             int64_t ntask = prefix.back();
+            append_coarse_index(prefix);
             if (ntask == 0) continue;
             nquart += ntask;
             if (prefix.size() > prefix_cap) {
@@ -1279,15 +1366,27 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             X.check_owner = nranks > 1; X.ni = E.ni; X.nj = E.nj; X.nk = E.nk; X.nl = E.nl;
             int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
             size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
+            const bool xf_mfma = mfma_worthwhile(X.nsab, X.nf, X.ne) || mfma_worthwhile(X.nsab, X.nscd, X.nf);
             if (shm2 > 64 * 1024)
-                HIPCHK(hipFuncSetAttribute((const void *)eri_transform_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
+                HIPCHK(hipFuncSetAttribute(xf_mfma ? (const void *)eri_transform_scatter<true> : (const void *)eri_transform_scatter<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
+            const bool dbg = getenv("MI355_DEBUG") != nullptr && getenv("MI355_DEBUG")[0] == '2';
+            double t_rys = 0.0, t_xf = 0.0;
             for (int64_t t0 = 0; t0 < ntask; t0 += per) {
                 int nb = (int)std::min<int64_t>(per, ntask - t0);
                 E.t0 = t0; E.ntask = nb; X.t0 = t0;
+                auto ta = std::chrono::steady_clock::now();
+                if (dbg) hipStreamSynchronize(st);
                 if (launch_eri(c, E, nb, st)) return -1;
-                hipLaunchKernelGGL(eri_transform_scatter, dim3(nb), dim3(64), shm2, st, X);
+                if (dbg) { hipStreamSynchronize(st); t_rys += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count(); ta = std::chrono::steady_clock::now(); }
+                if (xf_mfma) hipLaunchKernelGGL(eri_transform_scatter<true>, dim3(nb), dim3(64), shm2, st, X);
+                else hipLaunchKernelGGL(eri_transform_scatter<false>, dim3(nb), dim3(64), shm2, st, X);
                 HIPCHK(hipGetLastError());
+                if (dbg) { hipStreamSynchronize(st); t_xf += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count(); }
             }
+            if (dbg)
+                fprintf(stderr, "[mi355] eri class (%d%d|%d%d): %ld quartets, rys %.4f s (%.2f ns/q), transform+scatter %.4f s (%.2f ns/q)\n", B.la, B.lb,
+                        Kc.la, Kc.lb, (long)ntask, t_rys, t_rys / ntask * 1e9, t_xf, t_xf / ntask * 1e9);
         }
     HIPCHK(hipStreamSynchronize(st));
     lap("quartet evaluation");
@@ -2552,14 +2651,18 @@ struct GradXfArgs {
 };
 #define GRAD_COPIES 4096
 
-template <int GSZ> // lanes per quartet: 64, or 16 (four quartets per wave) for the small angular classes
-__global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
+// GSZ = lanes per quartet: 16 (four quartets per wave, small angular classes) or 64 (256 = four waves sharing one
+// quartet's LDS blocks is supported by the code but was measured slower and is not launched).
+template <int GSZ, bool MFMA>
+__global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfArgs A)
 {
     // sum_{x-independent part first}:  g[x] = sum_{r,e} M^x[r][e] * Z[r][e],  Z[r][e] = sum_f E0[e][f] Y[r][f],
     // Y[r][f] = sum_c G[r][c] Mcd[c][f]  -- contracting the two-particle density FIRST makes the work
     // independent of the derivative direction (3x fewer flops than forming the derivative integrals).
     extern __shared__ double lds_all[];
-    constexpr int QPW = 64 / GSZ;
+    constexpr int QPW = GSZ >= 64 ? 1 : 64 / GSZ;
+    constexpr int NW = GSZ >= 64 ? GSZ / 64 : 1;
+    const int wl = threadIdx.x & 63, wave = threadIdx.x >> 6; // lane within the wave / wave within the workgroup (MFMA tiles)
     const int grp = threadIdx.x / GSZ, lane = threadIdx.x % GSZ;
     const int64_t tl = (int64_t)blockIdx.x * QPW + grp; // task index inside this batch
     const bool in_batch = tl < A.nbatch;
@@ -2598,34 +2701,61 @@ __global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
         }
     }
     __syncthreads();
+    // the three small matrix products run on the FP64 MFMA pipe when the whole wave works on one quartet and the
+    // 16x16x4 padding does not eat the gain (wave-uniform decisions); otherwise plain per-lane dot products
     if (live) {
         const double *Mcd = A.Mbuf + cd.m_off;
-        for (int o = lane; o < nsab * nf; o += GSZ) {
-            int r = o / nf, f = o - r * nf;
-            double s = 0.0;
-            for (int c = 0; c < A.nscd; c++) s += G[r * A.nscd + c] * Mcd[c * nf + f];
-            Y[o] = s;
+        if (MFMA && GSZ >= 64 && mfma_worthwhile(nsab, nf, A.nscd)) {
+            int tile = 0;
+            for (int m0 = 0; m0 < nsab; m0 += 16)
+                for (int n0 = 0; n0 < nf; n0 += 16) {
+                    if ((tile++) % NW != wave) continue;
+                    d4_t y = wave_mfma_tile(G, A.nscd, 1, nsab, Mcd, nf, 1, nf, A.nscd, m0, n0, wl);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        int r = m0 + (wl >> 4) + 4 * q, f = n0 + (wl & 15);
+                        if (r < nsab && f < nf) Y[r * nf + f] = y[q];
+                    }
+                }
+        } else {
+            for (int o = lane; o < nsab * nf; o += GSZ) {
+                int r = o / nf, f = o - r * nf;
+                double s = 0.0;
+                for (int c = 0; c < A.nscd; c++) s += G[r * A.nscd + c] * Mcd[c * nf + f];
+                Y[o] = s;
+            }
         }
     }
     __syncthreads();
     double acc[3] = {0.0, 0.0, 0.0};
     if (live) {
-        const double *Mp = A.Mbuf + dp.m_off;
-        const size_t xs = (size_t)nsab * A.ne_p;
-        for (int o = lane; o < nsab * A.ne_p; o += GSZ) {
-            int r = o / A.ne_p, e = o - r * A.ne_p;
-            double z = 0.0;
-            for (int f = 0; f < nf; f++) z += E0p[e * nf + f] * Y[r * nf + f];
-            acc[0] += Mp[o] * z; acc[1] += Mp[xs + o] * z; acc[2] += Mp[2 * xs + o] * z;
-        }
-        if (has_m) {
-            const double *Mm = A.Mbuf + m_off_m;
-            const size_t xm = (size_t)nsab * A.ne_m;
-            for (int o = lane; o < nsab * A.ne_m; o += GSZ) {
-                int r = o / A.ne_m, e = o - r * A.ne_m;
-                double z = 0.0;
-                for (int f = 0; f < nf; f++) z += E0m[e * nf + f] * Y[r * nf + f];
-                acc[0] += Mm[o] * z; acc[1] += Mm[xm + o] * z; acc[2] += Mm[2 * xm + o] * z;
+        for (int var = 0; var < (has_m ? 2 : 1); var++) {
+            const double *Mx = A.Mbuf + (var == 0 ? dp.m_off : m_off_m);
+            const double *E0 = var == 0 ? E0p : E0m;
+            const int ne = var == 0 ? A.ne_p : A.ne_m;
+            const size_t xs = (size_t)nsab * ne;
+            if (MFMA && GSZ >= 64 && mfma_worthwhile(nsab, ne, nf)) {
+                int tile = 0;
+                for (int m0 = 0; m0 < nsab; m0 += 16)
+                    for (int n0 = 0; n0 < ne; n0 += 16) {
+                        if ((tile++) % NW != wave) continue;
+                        d4_t z = wave_mfma_tile(Y, nf, 1, nsab, E0, 1, nf, ne, nf, m0, n0, wl); // Z[r][e] = sum_f Y[r][f] E0[e][f]
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            int r = m0 + (wl >> 4) + 4 * q, e = n0 + (wl & 15);
+                            if (r < nsab && e < ne) {
+                                size_t o = (size_t)r * ne + e;
+                                acc[0] += Mx[o] * z[q]; acc[1] += Mx[xs + o] * z[q]; acc[2] += Mx[2 * xs + o] * z[q];
+                            }
+                        }
+                    }
+            } else {
+                for (int o = lane; o < nsab * ne; o += GSZ) {
+                    int r = o / ne, e = o - r * ne;
+                    double z = 0.0;
+                    for (int f = 0; f < nf; f++) z += E0[e * nf + f] * Y[r * nf + f];
+                    acc[0] += Mx[o] * z; acc[1] += Mx[xs + o] * z; acc[2] += Mx[2 * xs + o] * z;
+                }
             }
         }
     }
@@ -2635,8 +2765,8 @@ __global__ __launch_bounds__(64) void eri_grad_contract(GradXfArgs A)
     if (same_pair) w *= 0.5;
     for (int x = 0; x < 3; x++) {
         double v = acc[x];
-        for (int o = GSZ / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (live && lane == 0) {
+        for (int o = (GSZ < 64 ? GSZ : 64) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (live && (lane & ((GSZ < 64 ? GSZ : 64) - 1)) == 0) { // one partial sum per wave (per 16-lane group for GSZ = 16)
             double *gc = A.grad + (size_t)((blockIdx.x * QPW + grp) & (GRAD_COPIES - 1)) * A.natm3;
             atomicAdd(&gc[A.shell_atom[dp.sh_i] * 3 + x], w * v);
             // the skipped permutation (derivative on the first shell of the bra pair P) by invariance
@@ -2722,6 +2852,7 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                 prefix[b + 1] = prefix[b] + cnt;
             }
             int64_t ntask = prefix.back();
+            append_coarse_index(prefix);
             if (ntask == 0) continue;
             if (prefix.size() > prefix_cap) {
                 if (d_prefix) hipFree(d_prefix);
@@ -2785,11 +2916,16 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                     X.t0 = t0; X.nbatch = nb;
                     const int big = std::max({X.ns1 * X.ns2 * X.nscd, X.ns1 * X.ns2 * X.nf, X.ns1 * X.ns2 * X.ne_p});
                     if (big <= 48 && shm * 4 <= 64 * 1024) { // small classes: four quartets per wave (16 lanes each)
-                        hipLaunchKernelGGL(eri_grad_contract<16>, dim3((nb + 3) / 4), dim3(64), shm * 4, st, X);
+                        hipLaunchKernelGGL((eri_grad_contract<16, false>), dim3((nb + 3) / 4), dim3(64), shm * 4, st, X);
+                    } else if (mfma_worthwhile(X.ns1 * X.ns2, X.nf, X.nscd) || mfma_worthwhile(X.ns1 * X.ns2, X.ne_p, X.nf) ||
+                               (has_m && mfma_worthwhile(X.ns1 * X.ns2, X.ne_m, X.nf))) {
+                        if (shm > 64 * 1024)
+                            HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                        hipLaunchKernelGGL((eri_grad_contract<64, true>), dim3(nb), dim3(64), shm, st, X);
                     } else {
                         if (shm > 64 * 1024)
-                            HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                        hipLaunchKernelGGL(eri_grad_contract<64>, dim3(nb), dim3(64), shm, st, X);
+                            HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                        hipLaunchKernelGGL((eri_grad_contract<64, false>), dim3(nb), dim3(64), shm, st, X);
                     }
                     HIPCHK(hipGetLastError());
                 }
@@ -2823,8 +2959,6 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
 //   K split over the 4 waves of the workgroup, row panels staged in LDS; traces of Xc and X2c are
 //   accumulated with atomics into trc[2] for the next launch's branch decision.
 // =================================================================================================
-typedef double d4_t __attribute__((ext_vector_type(4)));
-
 __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *Xp, const double *X2p, const double *trp, int first,
                                                         int n, int kpad, double target, double *Xc, double *X2c, double *trc)
 {
