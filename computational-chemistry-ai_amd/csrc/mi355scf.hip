@@ -633,8 +633,9 @@ __device__ inline void find_task(const int64_t *prefix, int nbra, int64_t t, int
 // Does any AO quadruple of the shell quartet land in a tile that is resident on this rank?  (<= 16 block
 // combinations; every symmetry image of a quadruple maps to the same canonical tile.)
 __device__ inline bool quartet_has_resident_tile(const int32_t *table, int ao_i, int ni, int ao_j, int nj, int ao_k, int nk,
-                                                 int ao_l, int nl, int lane)
+                                                 int ao_l, int nl, int lane, int gsz = 64, int grp = 0)
 {
+    // `lane` is the lane inside a group of `gsz` (>= 16) lanes working on this quartet; groups vote separately
     bool hit = false;
     if (lane < 16) {
         int I = (lane & 1) ? (ao_i + ni - 1) >> 3 : ao_i >> 3;
@@ -647,40 +648,57 @@ __device__ inline bool quartet_has_resident_tile(const int32_t *table, int ao_i,
         int bmax = max(bij, bkl), bmin = min(bij, bkl);
         hit = table[(size_t)bmax * (bmax + 1) / 2 + bmin] >= 0;
     }
-    return __any(hit);
+    const unsigned long long votes = __ballot(hit);
+    const unsigned long long gmask = (gsz >= 64 ? ~0ull : ((1ull << gsz) - 1ull) << (gsz * grp));
+    return (votes & gmask) != 0ull;
 }
 
-template <int MAXC>
+// GSZ = lanes per shell quartet: 64, or 16 (four quartets per wave) for the low angular classes, whose handful of
+// components and roots leave a 64-lane wave idle while it waits on its chain of dependent loads.
+template <int MAXC, int GSZ>
 __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
 {
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const int64_t task = A.t0 + blockIdx.x;
+    extern __shared__ double lds_all[];
+    constexpr int QPW = 64 / GSZ;
+    const int grp = QPW == 1 ? 0 : threadIdx.x / GSZ, lane = QPW == 1 ? threadIdx.x : threadIdx.x % GSZ;
+    const int tl = blockIdx.x * QPW + grp; // task inside this launch
+    bool live = QPW == 1 || tl < A.ntask;
+    const int64_t task = A.t0 + (live ? tl : 0);
     int ib, ik;
     if (A.diag) { ib = (int)task; ik = ib; }
     else find_task(A.prefix, A.nbra, task, ib, ik);
     if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
-    if (A.own_table && !quartet_has_resident_tile(A.own_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane)) return;
-    if (A.dmax && A.q_bra[ib] * A.q_ket[ik] * quartet_density_bound(A.dmax, A.nbas_d, ab.sh_i, ab.sh_j, cd.sh_i, cd.sh_j, A.hyb) < A.dtol) return;
+    if (QPW == 1) { // one quartet per wave: negligible / non-resident quartets leave at once
+        if (A.own_table && !quartet_has_resident_tile(A.own_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane)) return;
+        if (A.dmax && A.q_bra[ib] * A.q_ket[ik] * quartet_density_bound(A.dmax, A.nbas_d, ab.sh_i, ab.sh_j, cd.sh_i, cd.sh_j, A.hyb) < A.dtol) return;
+    } else {
+        if (A.own_table)
+            live = quartet_has_resident_tile(A.own_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane, GSZ, grp) && live;
+        if (A.dmax && A.q_bra[ib] * A.q_ket[ik] * quartet_density_bound(A.dmax, A.nbas_d, ab.sh_i, ab.sh_j, cd.sh_i, cd.sh_j, A.hyb) < A.dtol) live = false;
+    }
     const int n = A.nroots, tsz = A.tsz, M1 = A.mmax + 1;
-    const int ncd = cd.nprim, nPQ = ab.nprim * ncd;
+    const int ncd = cd.nprim, nPQ = live ? ab.nprim * ncd : 0;
     const int PB = A.PB;
+    double *lds = QPW == 1 ? lds_all : lds_all + (size_t)grp * ((size_t)PB * n * 3 * tsz + (size_t)PB * 2 * n);
     double *T0 = lds;                       // [PB*n][3][tsz]
     double *rw = lds + (size_t)PB * n * 3 * tsz; // [PB][2n]
-    double *wout = A.work + (size_t)blockIdx.x * A.ncomp;
+    double *wout = A.work + (size_t)tl * A.ncomp;
+    int nPQ_all = nPQ; // uniform trip count over the quartets sharing this wave (the barriers below sit in the loop)
+    if (QPW > 1)
+        for (int o = GSZ; o < 64; o <<= 1) nPQ_all = max(nPQ_all, __shfl_xor(nPQ_all, o));
 
-    for (int c0 = 0; c0 < A.ncomp; c0 += 64 * MAXC) {
+    for (int c0 = 0; c0 < A.ncomp; c0 += GSZ * MAXC) {
         double acc[MAXC];
         uint32_t idx[MAXC];
 #pragma unroll
         for (int ci = 0; ci < MAXC; ci++) {
             acc[ci] = 0.0;
-            int c = c0 + ci * 64 + lane;
+            int c = c0 + ci * GSZ + lane;
             idx[ci] = (c < A.ncomp) ? A.comp[c] : 0xFFFFFFFFu;
         }
-        for (int pq0 = 0; pq0 < nPQ; pq0 += PB) {
-            const int npq = min(PB, nPQ - pq0);
+        for (int pq0 = 0; pq0 < nPQ_all; pq0 += PB) {
+            const int npq = QPW == 1 ? min(PB, nPQ - pq0) : max(0, min(PB, nPQ - pq0));
             // ---- phase R
             if (lane < npq * 2 * n) {
                 int pql = lane / (2 * n), f = lane - pql * 2 * n;
@@ -740,10 +758,12 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
             }
             __syncthreads();
         }
+        if (QPW == 1 || live) {
 #pragma unroll
-        for (int ci = 0; ci < MAXC; ci++) {
-            int c = c0 + ci * 64 + lane;
-            if (c < A.ncomp) wout[c] = acc[ci];
+            for (int ci = 0; ci < MAXC; ci++) {
+                int c = c0 + ci * GSZ + lane;
+                if (c < A.ncomp) wout[c] = acc[ci];
+            }
         }
     }
 }
@@ -787,7 +807,7 @@ struct XfArgs {
     const double *Mbuf;
     const int64_t *prefix;
     int nbra;
-    int64_t t0;
+    int64_t t0, ntask;       // this launch covers tasks [t0, t0+ntask)
     int ne, nf, nsab, nscd, nsb, nsd;
     const double *work;
     int ncomp;
@@ -816,22 +836,28 @@ __device__ inline void put_tile(const XfArgs &A, int i, int j, int k, int l, dou
 }
 
 // MFMA = true: instantiation with the matrix-core paths for the large angular classes; MFMA = false: lean kernel for
-// the small classes that make up most quartets.  One wave per quartet in both (four waves sharing a quartet's LDS
-// blocks were measured slower: 0.50 vs 0.46 s for ibuprofen/def2-TZVP).
-template <bool MFMA>
+// the small classes that make up most quartets.  GSZ = lanes per quartet (64, or 16 = four quartets per wave, as
+// in eri_rys_kernel).  (Four waves sharing a quartet's LDS blocks were measured slower: 0.50 vs 0.46 s for
+// ibuprofen/def2-TZVP.)
+template <bool MFMA, int GSZ>
 __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
 {
-    extern __shared__ double lds[];
-    constexpr int NT = 64, NW = NT / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ double lds_all[];
+    constexpr int QPW = 64 / GSZ;
+    const int grp = threadIdx.x / GSZ, lane = threadIdx.x % GSZ;
+    const int64_t tl = (int64_t)blockIdx.x * QPW + grp;
+    bool live = tl < A.ntask;
     int ib, ik;
-    find_task(A.prefix, A.nbra, A.t0 + blockIdx.x, ib, ik);
+    find_task(A.prefix, A.nbra, A.t0 + (live ? tl : 0), ib, ik);
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
-    if (A.check_owner && !quartet_has_resident_tile(A.tile_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane)) return;
-    const double *E0g = A.work + (size_t)blockIdx.x * A.ncomp;
-    double *E0 = lds;                 // [ne][nf]
-    double *X = lds + A.ne * A.nf;    // [nsab][nf]
-    for (int c = tid; c < A.ne * A.nf; c += NT) E0[c] = E0g[c];
+    if (A.check_owner)
+        live = quartet_has_resident_tile(A.tile_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane, GSZ, grp) && live;
+    if (QPW == 1 && !live) return;
+    const double *E0g = A.work + (size_t)tl * A.ncomp;
+    double *E0 = lds_all + (size_t)grp * ((size_t)A.ne * A.nf + (size_t)A.nsab * A.nf); // [ne][nf]
+    double *X = E0 + A.ne * A.nf;                                                       // [nsab][nf]
+    if (live)
+        for (int c = lane; c < A.ne * A.nf; c += GSZ) E0[c] = E0g[c];
     __syncthreads();
     const double *Mab = A.Mbuf + ab.m_off, *Mcd = A.Mbuf + cd.m_off;
     // which of the 8 index images can land in a canonical tile (I >= J, K >= L) at all: decided once per quartet
@@ -858,11 +884,9 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
         if (mask & 128) put_tile(A, l, k, j, i, s);
     };
     // X = Mab E0, out = X Mcd^T: FP64 MFMA tiles for the large angular classes, per-lane dot products otherwise
-    if (MFMA && mfma_worthwhile(A.nsab, A.nf, A.ne)) {
-        int tile = 0;
+    if (MFMA && GSZ == 64 && mfma_worthwhile(A.nsab, A.nf, A.ne)) {
         for (int m0 = 0; m0 < A.nsab; m0 += 16)
             for (int n0 = 0; n0 < A.nf; n0 += 16) {
-                if ((tile++) % NW != wave) continue;
                 d4_t x = wave_mfma_tile(Mab, A.ne, 1, A.nsab, E0, A.nf, 1, A.nf, A.ne, m0, n0, lane);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -870,8 +894,8 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
                     if (r < A.nsab && f < A.nf) X[r * A.nf + f] = x[q];
                 }
             }
-    } else {
-        for (int o = tid; o < A.nsab * A.nf; o += NT) {
+    } else if (live) {
+        for (int o = lane; o < A.nsab * A.nf; o += GSZ) {
             int r = o / A.nf, f = o - r * A.nf;
             double s = 0.0;
             for (int e = 0; e < A.ne; e++) s += Mab[r * A.ne + e] * E0[e * A.nf + f];
@@ -879,11 +903,9 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
         }
     }
     __syncthreads();
-    if (MFMA && mfma_worthwhile(A.nsab, A.nscd, A.nf)) {
-        int tile = 0;
+    if (MFMA && GSZ == 64 && mfma_worthwhile(A.nsab, A.nscd, A.nf)) {
         for (int m0 = 0; m0 < A.nsab; m0 += 16)
             for (int n0 = 0; n0 < A.nscd; n0 += 16) {
-                if ((tile++) % NW != wave) continue;
                 d4_t o4 = wave_mfma_tile(X, A.nf, 1, A.nsab, Mcd, 1, A.nf, A.nscd, A.nf, m0, n0, lane);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -891,8 +913,8 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
                     if (r < A.nsab && c < A.nscd) emit(r, c, o4[q]);
                 }
             }
-    } else {
-        for (int o = tid; o < A.nsab * A.nscd; o += NT) {
+    } else if (live) {
+        for (int o = lane; o < A.nsab * A.nscd; o += GSZ) {
             int r = o / A.nscd, c = o - r * A.nscd;
             double s = 0.0;
             for (int f = 0; f < A.nf; f++) s += X[r * A.nf + f] * Mcd[c * A.nf + f];
@@ -1017,14 +1039,27 @@ static int upload(T **dst, const std::vector<T> &v)
     return 0;
 }
 
+// Classes that run four quartets per wave (measured per class on ibuprofen/def2-TZVP: with more roots or components
+// the 16-lane groups need more primitive batches / passes than they win by overlapping four latency chains).
+static bool eri_small_class(const EriArgs &E) { return E.nroots <= 2 && E.ncomp <= 18; }
+
 static int launch_eri(mi_ctx *c, EriArgs &E, int nblocks, hipStream_t st)
 {
-    size_t shm = sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots);
+    // E.ntask tasks; the low angular classes run four quartets per wave (16 lanes each)
+    if (E.ntask != nblocks) return fail("launch_eri: ntask/grid mismatch");
     int perlane = (E.ncomp + 63) / 64;
-    if (perlane <= 1) hipLaunchKernelGGL(eri_rys_kernel<1>, dim3(nblocks), dim3(64), shm, st, E);
-    else if (perlane <= 4) hipLaunchKernelGGL(eri_rys_kernel<4>, dim3(nblocks), dim3(64), shm, st, E);
-    else if (perlane <= 16) hipLaunchKernelGGL(eri_rys_kernel<16>, dim3(nblocks), dim3(64), shm, st, E);
-    else hipLaunchKernelGGL(eri_rys_kernel<32>, dim3(nblocks), dim3(64), shm, st, E);
+    if (eri_small_class(E) && !E.diag) {
+        E.PB = std::max(1, 16 / (3 * E.nroots));
+        size_t shm = 4 * sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots);
+        hipLaunchKernelGGL((eri_rys_kernel<2, 16>), dim3((nblocks + 3) / 4), dim3(64), shm, st, E);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    size_t shm = sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots);
+    if (perlane <= 1) hipLaunchKernelGGL((eri_rys_kernel<1, 64>), dim3(nblocks), dim3(64), shm, st, E);
+    else if (perlane <= 4) hipLaunchKernelGGL((eri_rys_kernel<4, 64>), dim3(nblocks), dim3(64), shm, st, E);
+    else if (perlane <= 16) hipLaunchKernelGGL((eri_rys_kernel<16, 64>), dim3(nblocks), dim3(64), shm, st, E);
+    else hipLaunchKernelGGL((eri_rys_kernel<32, 64>), dim3(nblocks), dim3(64), shm, st, E);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1367,8 +1402,9 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
             size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
             const bool xf_mfma = mfma_worthwhile(X.nsab, X.nf, X.ne) || mfma_worthwhile(X.nsab, X.nscd, X.nf);
+            const bool xf_small = !xf_mfma && X.nsab * X.nscd <= 40 && shm2 * 4 <= 64 * 1024; // four quartets per wave
             if (shm2 > 64 * 1024)
-                HIPCHK(hipFuncSetAttribute(xf_mfma ? (const void *)eri_transform_scatter<true> : (const void *)eri_transform_scatter<false>,
+                HIPCHK(hipFuncSetAttribute(xf_mfma ? (const void *)eri_transform_scatter<true, 64> : (const void *)eri_transform_scatter<false, 64>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
             const bool dbg = getenv("MI355_DEBUG") != nullptr && getenv("MI355_DEBUG")[0] == '2';
             double t_rys = 0.0, t_xf = 0.0;
@@ -1379,8 +1415,10 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                 if (dbg) hipStreamSynchronize(st);
                 if (launch_eri(c, E, nb, st)) return -1;
                 if (dbg) { hipStreamSynchronize(st); t_rys += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count(); ta = std::chrono::steady_clock::now(); }
-                if (xf_mfma) hipLaunchKernelGGL(eri_transform_scatter<true>, dim3(nb), dim3(64), shm2, st, X);
-                else hipLaunchKernelGGL(eri_transform_scatter<false>, dim3(nb), dim3(64), shm2, st, X);
+                X.ntask = nb;
+                if (xf_mfma) hipLaunchKernelGGL((eri_transform_scatter<true, 64>), dim3(nb), dim3(64), shm2, st, X);
+                else if (xf_small) hipLaunchKernelGGL((eri_transform_scatter<false, 16>), dim3((nb + 3) / 4), dim3(64), shm2 * 4, st, X);
+                else hipLaunchKernelGGL((eri_transform_scatter<false, 64>), dim3(nb), dim3(64), shm2, st, X);
                 HIPCHK(hipGetLastError());
                 if (dbg) { hipStreamSynchronize(st); t_xf += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count(); }
             }

@@ -8,7 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "computational-chemistry-ai_amd", "python"))
 import numpy as np, torch
 from mi355scf.mole import Mole
+from mi355scf import engine as _engine_mod
 from mi355scf.engine import Engine
+if os.environ.get("MI355SCF_LIB"):   # A/B runs of two builds on the same box
+    _engine_mod.LIB_PATH = os.path.abspath(os.environ["MI355SCF_LIB"])
 from mi355scf import smiles_fixtures, fixtures
 name, basis = sys.argv[1], sys.argv[2]
 def _atoms(key):
