@@ -200,6 +200,9 @@ struct PairClass {
     std::vector<double> q;         // Schwarz bound per rec
     PairRec *d_recs = nullptr;
     double *d_q = nullptr;
+    // primitive-pair counts of the sorted list: mean, and mean over windows of 4 consecutive pairs of the window maximum
+    // (four consecutive tasks share a wave in the 16-lane-group kernels and run as long as the longest of them)
+    double mean_np = 1.0, max4_np = 1.0;
 };
 
 struct TileInfo { int I, J, K, L; };
@@ -604,6 +607,8 @@ struct EriArgs {
     const double *q_bra, *q_ket, *dmax; // Schwarz factors of the two pair lists; max |D| per shell pair [nbas][nbas]
     int nbas_d;
     double dtol, hyb;
+    // host side only (kernel choice): primitive-pair statistics of the shared (bra) and the varying (ket) pair list
+    double h_shared_np, h_vary_mean, h_vary_max4;
 };
 
 // Upper bound of |G| = |D_ab D_cd - hyb/4 (D_ac D_bd + D_ad D_bc)| over the AO quadruples of a shell quartet.
@@ -1045,15 +1050,22 @@ static bool eri_small_class(const EriArgs &E) { return E.nroots <= 2 && E.ncomp 
 
 static int launch_eri(mi_ctx *c, EriArgs &E, int nblocks, hipStream_t st)
 {
-    // E.ntask tasks; the low angular classes run four quartets per wave (16 lanes each)
+    // E.ntask tasks; the low angular classes run four quartets per wave (16 lanes each) unless their contraction depth
+    // makes the four quartets of a wave too unequal: cost model in primitive batches per four quartets
     if (E.ntask != nblocks) return fail("launch_eri: ntask/grid mismatch");
     int perlane = (E.ncomp + 63) / 64;
-    if (eri_small_class(E) && !E.diag) {
-        E.PB = std::max(1, 16 / (3 * E.nroots));
-        size_t shm = 4 * sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots);
-        hipLaunchKernelGGL((eri_rys_kernel<2, 16>), dim3((nblocks + 3) / 4), dim3(64), shm, st, E);
-        HIPCHK(hipGetLastError());
-        return 0;
+    if (eri_small_class(E) && !E.diag && E.h_shared_np > 0.0) {
+        const int pb16 = std::max(1, 16 / (3 * E.nroots)), pb64 = std::max(1, 64 / (3 * E.nroots));
+        const double cost16 = std::ceil(E.h_shared_np * E.h_vary_max4 / pb16) + 1.5;
+        const double cost64 = 4.0 * (std::ceil(E.h_shared_np * E.h_vary_mean / pb64) + 1.5);
+        if (cost16 < cost64) {
+            EriArgs G = E;
+            G.PB = pb16;
+            size_t shm = 4 * sizeof(double) * ((size_t)G.PB * G.nroots * 3 * G.tsz + (size_t)G.PB * 2 * G.nroots);
+            hipLaunchKernelGGL((eri_rys_kernel<2, 16>), dim3((nblocks + 3) / 4), dim3(64), shm, st, G);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
     }
     size_t shm = sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots);
     if (perlane <= 1) hipLaunchKernelGGL((eri_rys_kernel<1, 64>), dim3(nblocks), dim3(64), shm, st, E);
@@ -1216,6 +1228,18 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         P.q.swap(q2);
         if (upload(&P.d_recs, P.recs)) return -1;
         if (upload(&P.d_q, P.q)) return -1; // Schwarz factors in the sorted order (density-weighted screening of the gradient)
+        {
+            double sm = 0.0, s4 = 0.0;
+            const size_t np_ = P.recs.size();
+            for (size_t r = 0; r < np_; r++) sm += P.recs[r].nprim;
+            for (size_t r = 0; r < np_; r += 4) {
+                int mx = 0;
+                for (size_t u = r; u < std::min(np_, r + 4); u++) mx = std::max(mx, P.recs[u].nprim);
+                s4 += mx;
+            }
+            P.mean_np = np_ ? sm / np_ : 1.0;
+            P.max4_np = np_ ? s4 / ((np_ + 3) / 4) : 1.0;
+        }
     }
 
     lap("sort pairs");
@@ -1393,6 +1417,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             E.comp = d_comp; E.work = d_work; E.rys = c->rys; E.diag = 0;
             E.ni = 2 * B.la + 1; E.nj = 2 * B.lb + 1; E.nk = 2 * Kc.la + 1; E.nl = 2 * Kc.lb + 1;
             E.own_table = nranks > 1 ? c->d_tile_table : nullptr;
+            E.h_shared_np = B.mean_np; E.h_vary_mean = Kc.mean_np; E.h_vary_max4 = Kc.max4_np;
             XfArgs X{};
             X.bra = B.d_recs; X.ket = Kc.d_recs; X.Mbuf = c->d_M; X.prefix = d_prefix; X.nbra = E.nbra;
             X.ne = B.ne; X.nf = Kc.ne; X.nsab = B.nsab; X.nscd = Kc.nsab; X.nsb = 2 * B.lb + 1; X.nsd = 2 * Kc.lb + 1;
@@ -2927,6 +2952,8 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                     Em.bra = Dc.d_g_recs[orient][1]; Em.ket = Oc.d_recs; Em.prim = c->d_prim; Em.prefix = d_prefix; Em.nbra = Ep.nbra;
                     Em.comp = d_comp_m; Em.work = d_wm; Em.rys = c->rys; Em.diag = 0; Em.swap = Ep.swap;
                 }
+                Ep.h_shared_np = B.mean_np; Ep.h_vary_mean = Kc.mean_np; Ep.h_vary_max4 = Kc.max4_np;
+                Em.h_shared_np = B.mean_np; Em.h_vary_mean = Kc.mean_np; Em.h_vary_max4 = Kc.max4_np;
                 Ep.q_bra = Dc.d_q; Ep.q_ket = Oc.d_q; Ep.dmax = d_dmax; Ep.nbas_d = c->nbas; Ep.dtol = c->opt_grad_dtol; Ep.hyb = hyb;
                 if (has_m) { Em.q_bra = Ep.q_bra; Em.q_ket = Ep.q_ket; Em.dmax = d_dmax; Em.nbas_d = c->nbas; Em.dtol = Ep.dtol; Em.hyb = hyb; }
                 GradXfArgs X{};
