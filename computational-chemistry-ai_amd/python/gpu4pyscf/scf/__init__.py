@@ -1,2 +1,3 @@
-from . import hf  # noqa: F401
+from . import hf, uhf  # noqa: F401
 RHF = hf.RHF
+UHF = uhf.UHF

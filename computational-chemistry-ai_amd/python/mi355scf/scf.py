@@ -125,14 +125,15 @@ class SCF:
     _sp2_iters = 24
     _sp2_validated = False   # True once an iteration count has passed the checked path for this Fock spectrum
     sp2_fused_max = 160  # measured: fused wins at N=114 (0.92 -> 0.80 ms/cycle), rocBLAS wins at N=264
+    _spin_restricted = True
 
     def __init__(self, mol):
         if not isinstance(mol, Mole):
             raise TypeError("SCF needs a built gto.Mole")
         if not mol._built:
             mol.build()
-        if mol.spin != 0:
-            raise NotImplementedError("only closed-shell RHF/RKS is on the MI355X hot path (SURVEY.md section 8f rank 4)")
+        if mol.spin != 0 and self._spin_restricted:
+            raise NotImplementedError("RHF/RKS need a closed shell (mol.spin = 0); use scf.UHF / dft.UKS for open shells")
         self.mol = mol
         self.verbose = mol.verbose
         self.stdout = mol.stdout

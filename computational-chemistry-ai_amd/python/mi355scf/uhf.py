@@ -1,0 +1,217 @@
+"""Spin-unrestricted SCF behind `pyscf.scf.UHF` / `gpu4pyscf.scf.UHF` and `dft.UKS` (SURVEY.md section 8f
+rank 4; call sites `templates/calculate_bde.py:126-128,138-140,189-215`: radicals with `mol.spin = 1`).
+
+Same engine as RHF: both spin densities go through the resident-tile J/K kernel in one call
+(`mi_build_jk(n_dm = 2)`; J = J[Da] + J[Db], K_s = K[D_s]), sharded runs all-reduce the [J|K] buffer once.
+F_s = h + J - c_x K_s (+ V_xc,s for UKS), E = 1/2 sum_s tr D_s (h + F_s^HF) (+ E_xc).  CDIIS acts on the pair
+(F_a, F_b) with the concatenated error vectors F_s D_s S - S D_s F_s; the orbitals of each spin come from one
+`eigh` of the Cholesky-orthogonalised Fock matrix per cycle (aufbau occupation, n_alpha >= n_beta).
+"""
+import time
+
+import numpy as np
+import torch
+
+from .scf import SCF
+
+
+class PairDIIS:
+    """Pulay CDIIS on stacked [2, N, N] Fock/error matrices (device history, host (m+1)x(m+1) solve)."""
+
+    def __init__(self, space=8):
+        self.space, self.F, self.E = space, [], []
+
+    def update(self, f, e):
+        self.F.append(f.clone()); self.E.append(e.clone())
+        if len(self.F) > self.space:
+            self.F.pop(0); self.E.pop(0)
+        m = len(self.F)
+        Es = torch.stack([x.reshape(-1) for x in self.E])
+        B = (Es @ Es.T).cpu().numpy()
+        A = np.zeros((m + 1, m + 1))
+        A[0, 1:] = A[1:, 0] = 1.0
+        A[1:, 1:] = B
+        rhs = np.zeros(m + 1)
+        rhs[0] = 1.0
+        try:
+            c = np.linalg.solve(A, rhs)
+        except np.linalg.LinAlgError:
+            c = np.linalg.lstsq(A, rhs, rcond=None)[0]
+        out = torch.zeros_like(f)
+        for ci, fi in zip(c[1:], self.F):
+            out += float(ci) * fi
+        return out
+
+
+class UHF(SCF):
+    _spin_restricted = False
+
+    def __init__(self, mol):
+        SCF.__init__(self, mol)
+        self.nelec = mol.nelec
+
+    # --- densities ------------------------------------------------------------------------------
+    def make_rdm1(self, mo_coeff=None, mo_occ=None):
+        if mo_coeff is None:
+            if self._dm is not None:
+                return self._dm.cpu().numpy()
+            mo_coeff, mo_occ = self.mo_coeff, self.mo_occ
+        out = []
+        for c, o in zip(np.asarray(mo_coeff), np.asarray(mo_occ)):
+            co = c[:, o > 0]
+            out.append((co * o[o > 0]) @ co.T)
+        return np.stack(out)
+
+    def get_init_guess(self, mol=None, key=None):
+        """Spin-restricted guess density split by electron count: D_s = D n_s / N (the first diagonalisation
+        with n_alpha != n_beta occupations separates the spins)."""
+        key = key if key is not None else self.init_guess
+        if isinstance(key, np.ndarray) and key.ndim == 3:
+            return key
+        d = np.asarray(SCF.get_init_guess(self, mol, key))
+        if d.ndim == 3:
+            return d
+        na, nb = self.nelec
+        ne = max(na + nb, 1)
+        return np.stack([d * (na / ne), d * (nb / ne)])
+
+    # --- Fock pieces ----------------------------------------------------------------------------
+    def _fock_pair(self, dm):
+        """(F[2,N,N], E_elec) on device for the spin densities dm[2,N,N].  Overridden by UKS."""
+        J, K = self._jk(dm)
+        Jt = J[0] + J[1]
+        F = self._h1.unsqueeze(0) + Jt.unsqueeze(0) - K
+        e = 0.5 * torch.sum(dm * (self._h1.unsqueeze(0) + F))
+        return F, e
+
+    def get_veff(self, mol=None, dm=None, **kw):
+        if dm is None:
+            dm = self.make_rdm1()
+        self._setup_once()
+        d = torch.as_tensor(np.asarray(dm), dtype=torch.float64, device=self.engine.device)
+        F, _ = self._fock_pair(d)
+        return (F - self._h1.unsqueeze(0)).cpu().numpy()
+
+    def energy_tot(self, dm=None, h1e=None, vhf=None):
+        if dm is None:
+            return self.e_tot
+        self._setup_once()
+        d = torch.as_tensor(np.asarray(dm), dtype=torch.float64, device=self.engine.device)
+        return float(self._fock_pair(d)[1]) + self.mol.energy_nuc()
+
+    def spin_square(self, mo_coeff=None, s=None):
+        """<S^2> and 2S+1 of the UHF determinant: S_z(S_z+1) + n_beta - sum_ij |<i_a|j_b>|^2."""
+        mo = np.asarray(self.mo_coeff if mo_coeff is None else mo_coeff)
+        occ = np.asarray(self.mo_occ)
+        S = self.get_ovlp() if s is None else s
+        ca, cb = mo[0][:, occ[0] > 0], mo[1][:, occ[1] > 0]
+        na, nb = ca.shape[1], cb.shape[1]
+        sab = ca.T @ S @ cb
+        sz = 0.5 * (na - nb)
+        ss = sz * (sz + 1.0) + nb - float(np.sum(sab * sab))
+        return ss, float(np.sqrt(4.0 * ss + 1.0))
+
+    # --- SCF loop -------------------------------------------------------------------------------
+    def kernel(self, dm0=None, **kw):
+        t_start = time.time()
+        mol = self.mol
+        self._setup_once()
+        eng = self.engine
+        S, L, Li = self._S, self._L, self._Linv
+        na, nb = mol.nelec
+        self.nelec = (na, nb)
+        n = eng.nao
+        if dm0 is None:
+            dm0 = self.get_init_guess()
+        dm0 = np.asarray(dm0)
+        if dm0.ndim == 2:
+            ne = max(na + nb, 1)
+            dm0 = np.stack([dm0 * (na / ne), dm0 * (nb / ne)])
+        dm = torch.as_tensor(dm0, dtype=torch.float64, device=eng.device).contiguous()
+        enuc = mol.energy_nuc()
+        conv_tol = self.conv_tol
+        conv_tol_grad = self.conv_tol_grad if self.conv_tol_grad is not None else np.sqrt(conv_tol)
+        diis = PairDIIS(self.diis_space)
+        F, e_el = self._fock_pair(dm)
+        e_tot = float(e_el) + enuc
+        self._log(4, f"init E= {e_tot:.15g}")
+        self.converged = False
+        cycle = 0
+        t_loop = time.time()
+        mo_e = mo_c = None
+
+        def orbitals(Fx):
+            es, cs = [], []
+            for s_ in range(2):
+                e_, c_ = torch.linalg.eigh(Li @ Fx[s_] @ Li.T)
+                es.append(e_); cs.append(Li.T @ c_)
+            return torch.stack(es), torch.stack(cs)
+
+        def density(cs):
+            ca, cb = cs[0][:, :na], cs[1][:, :nb]
+            return torch.stack([ca @ ca.T, cb @ cb.T])
+
+        nvo = max(na * (n - na) + nb * (n - nb), 1)
+        de = gnorm = 0.0
+        while cycle < self.max_cycle:
+            err = torch.stack([F[s_] @ dm[s_] @ S - S @ dm[s_] @ F[s_] for s_ in range(2)])
+            Fx = diis.update(F, err) if cycle + 1 >= self.diis_start_cycle else F
+            mo_e, mo_c = orbitals(Fx)
+            dm = density(mo_c)
+            F, e_el = self._fock_pair(dm)
+            e_new = float(e_el) + enuc
+            # orbital gradient of the NEW Fock matrix in the new orbitals: occupied-virtual blocks of both spins
+            g2 = 0.0
+            for s_, no in ((0, na), (1, nb)):
+                fmo = mo_c[s_].T @ F[s_] @ mo_c[s_]
+                g2 = g2 + torch.sum(fmo[no:, :no] ** 2)
+            gnorm = float(torch.sqrt(g2)) / np.sqrt(nvo)
+            de = e_new - e_tot
+            e_tot = e_new
+            cycle += 1
+            self._log(4, f"cycle= {cycle} E= {e_tot:.15g}  delta_E= {de:.3g}  |g|= {gnorm:.3g}")
+            if abs(de) < conv_tol and gnorm < conv_tol_grad:
+                self.converged = True
+                break
+        self.cycles = cycle
+        self.timing["loop_seconds"] = time.time() - t_loop
+        if self.converged and self.conv_check:
+            mo_e, mo_c = orbitals(F)
+            dm = density(mo_c)
+            F, e_el = self._fock_pair(dm)
+            e_new = float(e_el) + enuc
+            self._log(4, f"Extra cycle  E= {e_new:.15g}  delta_E= {e_new - e_tot:.3g}")
+            e_tot = e_new
+        if mo_e is None:
+            mo_e, mo_c = orbitals(F)
+        self._dm, self._fock = dm, F
+        self.e_tot = e_tot
+        self.mo_energy = mo_e.cpu().numpy()
+        self.mo_coeff = mo_c.cpu().numpy()
+        occ = np.zeros((2, n))
+        occ[0, :na] = 1.0
+        occ[1, :nb] = 1.0
+        self.mo_occ = occ
+        self.timing["total_seconds"] = time.time() - t_start
+        if self.converged:
+            ss, mult = self.spin_square()
+            self._log(3, f"converged SCF energy = {self.e_tot:.15g}  <S^2> = {ss:.8g}  2S+1 = {mult:.8g}")
+        else:
+            self._log(3, f"SCF not converged.\nSCF energy = {self.e_tot:.15g} after {self.max_cycle} cycles")
+        return self.e_tot
+
+    scf = kernel
+
+    def dip_moment(self, mol=None, dm=None, unit="Debye", verbose=None, **kw):
+        if dm is None:
+            dm = self.make_rdm1()
+        dm = np.asarray(dm)
+        if dm.ndim == 3:
+            dm = dm[0] + dm[1]
+        return SCF.dip_moment(self, mol, dm, unit, verbose, **kw)
+
+    def nuc_grad_method(self):
+        from . import grad
+        return grad.UGradients(self)
+
+    Gradients = nuc_grad_method

@@ -1,5 +1,3 @@
-class UHF:
-    """Open-shell SCF is outside the MI355X hot path; the class exists
-    because `templates/optimize_geometry.py:117` names it in an isinstance check."""
-    def __init__(self, *a, **k):
-        raise NotImplementedError("UHF is not implemented in the MI355X engine (closed-shell RHF/RKS only)")
+"""`pyscf.scf.uhf`: `UHF` (reference call sites `templates/calculate_bde.py:138,210`; named in the isinstance
+check at `templates/optimize_geometry.py:117`)."""
+from mi355scf.uhf import UHF  # noqa: F401

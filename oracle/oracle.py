@@ -197,3 +197,58 @@ def rhf(mol, dm0=None, conv_tol=1e-9, max_cycle=50, veff_fn=None, verbose=False,
     mo_occ[:nocc] = 2.0
     return dict(e_tot=e_tot, converged=converged, mo_energy=mo_e, mo_coeff=mo_c, mo_occ=mo_occ, dm=dm,
                 cycles=cycles, S=S, h=h, vhf=vhf)
+
+
+def uhf(mol, conv_tol=1e-10, max_cycle=100, dm0=None, verbose=False):
+    """Spin-unrestricted HF on the CPU oracle integrals (checker for `mi355scf.uhf.UHF`): F_s = h + J[Da+Db] - K[D_s],
+    CDIIS on the stacked (F_a, F_b), aufbau occupations n_alpha >= n_beta.  dm0: [2,N,N] or a total density [N,N]
+    (split by electron count) or None (core-Hamiltonian guess).  Returns (e_tot, (Da, Db), (ea, eb), (Ca, Cb))."""
+    o = Oracle(mol)
+    S, T, V, _ = o.int1e()
+    h = T + V
+    na, nb = mol.nelec
+    enuc = mol.energy_nuc()
+
+    def dens(F):
+        out, es, cs = [], [], []
+        for s_, no in ((0, na), (1, nb)):
+            e, c = eig_gen(F[s_], S)
+            out.append(c[:, :no] @ c[:, :no].T); es.append(e); cs.append(c)
+        return np.stack(out), es, cs
+
+    if dm0 is None:
+        dm, _, _ = dens(np.stack([h, h]))
+    else:
+        dm0 = np.asarray(dm0)
+        dm = dm0 if dm0.ndim == 3 else np.stack([dm0 * na / max(na + nb, 1), dm0 * nb / max(na + nb, 1)])
+
+    def fock(dm):
+        Ja, Ka = o.jk(dm[0], tol=0.0)
+        Jb, Kb = o.jk(dm[1], tol=0.0)
+        F = np.stack([h + Ja + Jb - Ka, h + Ja + Jb - Kb])
+        return F, 0.5 * float(np.sum(dm * (h[None] + F))) + enuc
+
+    F, e = fock(dm)
+    Fh, Eh = [], []
+    es = cs = None
+    for it in range(max_cycle):
+        err = np.stack([F[s_] @ dm[s_] @ S - S @ dm[s_] @ F[s_] for s_ in range(2)])
+        Fh.append(F.copy()); Eh.append(err.ravel().copy())
+        Fh, Eh = Fh[-8:], Eh[-8:]
+        m = len(Fh)
+        A = np.zeros((m + 1, m + 1)); A[0, 1:] = A[1:, 0] = 1.0
+        A[1:, 1:] = np.array([[a @ b for b in Eh] for a in Eh])
+        rhs = np.zeros(m + 1); rhs[0] = 1.0
+        c = np.linalg.lstsq(A, rhs, rcond=None)[0]
+        Fx = sum(ci * Fi for ci, Fi in zip(c[1:], Fh))
+        dm, es, cs = dens(Fx)
+        F, e_new = fock(dm)
+        if verbose:
+            print(f"oracle uhf cycle {it + 1}: E = {e_new:.12f}  dE = {e_new - e:.3e}  |err| = {np.abs(err).max():.3e}")
+        done = abs(e_new - e) < conv_tol and np.abs(err).max() < 1e-6
+        e = e_new
+        if done:
+            break
+    dm, es, cs = dens(F)
+    F, e = fock(dm)
+    return e, dm, es, cs
