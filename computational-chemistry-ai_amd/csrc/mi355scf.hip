@@ -2700,7 +2700,8 @@ struct GradXfArgs {
     int ne_p, ne_m, nf, ns1, ns2, nscd, nsd;
     const double *work_p, *work_m;
     int ncomp_p, ncomp_m;
-    const double *D; // padded
+    const double *D; // padded total density
+    const double *Dm; // padded spin density Da - Db (UHF/UKS) or nullptr
     int ld;
     double hyb;
     const int *shell_atom;
@@ -2759,8 +2760,10 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
             int r = o / A.nscd, c = o - r * A.nscd;
             int sa = r / A.ns2, sb = r - sa * A.ns2, sc = c / A.nsd, sd = c - sc * A.nsd;
             int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
-            G[o] = D[(size_t)i * ld + j] * D[(size_t)k * ld + l] -
-                   0.25 * A.hyb * (D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k]);
+            double ex = D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k];
+            if (A.Dm) // sum_s Ds x Ds = (D x D + M x M) / 2
+                ex += A.Dm[(size_t)i * ld + k] * A.Dm[(size_t)j * ld + l] + A.Dm[(size_t)i * ld + l] * A.Dm[(size_t)j * ld + k];
+            G[o] = D[(size_t)i * ld + j] * D[(size_t)k * ld + l] - 0.25 * A.hyb * ex;
         }
     }
     __syncthreads();
@@ -2839,14 +2842,18 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
 }
 
 // max |D| over the AO block of every shell pair (density-weighted screening of the derivative quartets)
-__global__ void shell_dmax_kernel(const double *D, int ld, const int *sh_ao, const int *sh_n, int nbas, double *out)
+__global__ void shell_dmax_kernel(const double *D, const double *Dm, int ld, const int *sh_ao, const int *sh_n, int nbas, double *out)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nbas * nbas) return;
     int a = idx / nbas, b = idx - a * nbas;
     double m = 0.0;
     for (int i = 0; i < sh_n[a]; i++)
-        for (int j = 0; j < sh_n[b]; j++) m = fmax(m, fabs(D[(size_t)(sh_ao[a] + i) * ld + sh_ao[b] + j]));
+        for (int j = 0; j < sh_n[b]; j++) {
+            size_t o = (size_t)(sh_ao[a] + i) * ld + sh_ao[b] + j;
+            // open shell: |D| + |M| bounds both spin densities (the exchange bound then covers D x D + M x M)
+            m = fmax(m, fabs(D[o]) + (Dm ? fabs(Dm[o]) : 0.0));
+        }
     out[idx] = m;
 }
 
@@ -2859,7 +2866,14 @@ __global__ void grad_reduce_copies_kernel(const double *copies, int natm3, doubl
     grad[idx] += s;
 }
 
+extern "C" int mi_grad_eri_spin(mi_ctx *c, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, void *stream);
+
 extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_grad, void *stream)
+{
+    return mi_grad_eri_spin(c, d_D, nullptr, hyb, d_grad, stream);
+}
+
+extern "C" int mi_grad_eri_spin(mi_ctx *c, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, void *stream)
 {
     if (!c || !d_D || !d_grad) return fail("mi_grad_eri: null argument");
     if (!c->eri_ready) return fail("mi_grad_eri: call mi_eri_prepare first");
@@ -2870,6 +2884,11 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
     auto tg1 = std::chrono::steady_clock::now();
     size_t pp = (size_t)c->ldp * c->ldp;
     hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->nao, c->ldp);
+    double *d_Mpad = nullptr; // spin density Da - Db, padded like D (open shell only)
+    if (d_Dspin) {
+        HIPCHK(hipMalloc(&d_Mpad, sizeof(double) * pp));
+        hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_Dspin, d_Mpad, c->nao, c->ldp);
+    }
     std::vector<int> shell_atom(c->nbas);
     for (int i = 0; i < c->nbas; i++) shell_atom[i] = c->shells[i].atom;
     int *d_shell_atom = nullptr;
@@ -2882,7 +2901,7 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
         for (int i = 0; i < c->nbas; i++) { sh_ao[i] = c->shells[i].ao; sh_n[i] = 2 * c->shells[i].l + 1; }
         if (upload(&d_sh_ao, sh_ao) || upload(&d_sh_n, sh_n)) return -1;
         HIPCHK(hipMalloc(&d_dmax, sizeof(double) * (size_t)c->nbas * c->nbas));
-        hipLaunchKernelGGL(shell_dmax_kernel, dim3((c->nbas * c->nbas + 255) / 256), dim3(256), 0, st, c->d_Dpad, c->ldp, d_sh_ao, d_sh_n,
+        hipLaunchKernelGGL(shell_dmax_kernel, dim3((c->nbas * c->nbas + 255) / 256), dim3(256), 0, st, c->d_Dpad, d_Mpad, c->ldp, d_sh_ao, d_sh_n,
                            c->nbas, d_dmax);
         HIPCHK(hipGetLastError());
     }
@@ -2963,7 +2982,7 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
                 X.ne_p = ne_of(l1 + 1, l2); X.ne_m = has_m ? ne_of(l1 - 1, l2) : 0; X.nf = Oc.ne;
                 X.ns1 = 2 * l1 + 1; X.ns2 = 2 * l2 + 1; X.nscd = Oc.nsab; X.nsd = 2 * Oc.lb + 1;
                 X.work_p = d_wp; X.work_m = d_wm; X.ncomp_p = Ep.ncomp; X.ncomp_m = has_m ? Em.ncomp : 0;
-                X.D = c->d_Dpad; X.ld = c->ldp; X.hyb = hyb; X.shell_atom = d_shell_atom; X.grad = d_gcopies; X.natm3 = natm3;
+                X.D = c->d_Dpad; X.Dm = d_Mpad; X.ld = c->ldp; X.hyb = hyb; X.shell_atom = d_shell_atom; X.grad = d_gcopies; X.natm3 = natm3;
                 X.inv_from_second = swap ? 0 : 1;
                 size_t shm = sizeof(double) * ((size_t)X.ne_p * X.nf + (size_t)X.ne_m * X.nf + (size_t)X.ns1 * X.ns2 * (X.nf + X.nscd));
                 if (shm > 160 * 1024) return fail("gradient contraction needs %zu bytes of LDS", shm);
@@ -3011,6 +3030,7 @@ extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_g
     if (d_prefix) hipFree(d_prefix);
     hipFree(d_wp); hipFree(d_wm); hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_shell_atom);
     if (d_dmax) hipFree(d_dmax);
+    if (d_Mpad) hipFree(d_Mpad);
     if (d_sh_ao) hipFree(d_sh_ao);
     if (d_sh_n) hipFree(d_sh_n);
     return 0;

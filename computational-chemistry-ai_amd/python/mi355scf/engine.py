@@ -74,6 +74,7 @@ def lib():
         L.mi_sp2_iterate.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, ctypes.POINTER(vp), vp]
         L.mi_grad_1e.argtypes = [vp, vp, vp, vp, vp]
         L.mi_grad_eri.argtypes = [vp, vp, ctypes.c_double, vp, vp]
+        L.mi_grad_eri_spin.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_fock_energy.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp]
         L.mi_commutator_norm.argtypes = [vp, vp, vp, vp, vp]
         L.mi_c2s_table.argtypes = [ctypes.c_int, dp]
@@ -251,10 +252,12 @@ class Engine:
     def grad_1e(self, D, W, grad):
         _check(lib().mi_grad_1e(self._h, D.data_ptr(), W.data_ptr(), grad.data_ptr(), self._stream()))
 
-    def grad_eri(self, D, hyb, grad):
+    def grad_eri(self, D, hyb, grad, spin_density=None):
+        """D: total density; spin_density: Da - Db for UHF/UKS (None: closed shell)."""
         if not self.eri_ready:
             self.prepare_eri()
-        _check(lib().mi_grad_eri(self._h, D.data_ptr(), float(hyb), grad.data_ptr(), self._stream()))
+        _check(lib().mi_grad_eri_spin(self._h, D.data_ptr(), spin_density.data_ptr() if spin_density is not None else None,
+                                      float(hyb), grad.data_ptr(), self._stream()))
 
     # --- row a11: SP2 purification helpers ------------------------------------------------------
     def sp2_init(self, f_orth, X, work):

@@ -125,6 +125,51 @@ class Gradients:
         return _GradScanner(self)
 
 
+class UGradients(Gradients):
+    """Analytic UHF gradient: the restricted pieces with D = Da + Db, W = sum_s Ds Fs Ds, and the exchange part of
+    the two-particle density from both spins (`mi_grad_eri_spin`, spin density M = Da - Db)."""
+
+    def kernel(self, mo_energy=None, mo_coeff=None, mo_occ=None, atmlst=None):
+        mf = self.base
+        if mf._dm is None or not mf.converged:
+            mf.kernel()
+        eng = mf.engine
+        mol = mf.mol
+        dma, dmb = mf._dm[0], mf._dm[1]
+        F = mf._fock
+        D = (dma + dmb).contiguous()
+        M = (dma - dmb).contiguous()
+        W = (dma @ F[0] @ dma + dmb @ F[1] @ dmb).contiguous()
+        g = torch.zeros(mol.natm, 3, dtype=torch.float64, device=eng.device)
+        eng.grad_1e(D, W, g)
+        is_ks = getattr(mf, "xc", None) is not None and hasattr(mf, "grids")
+        hyb = 1.0
+        if is_ks:
+            from .dft import parse_xc
+            hyb = parse_xc(mf.xc)[0]
+        g2 = torch.zeros_like(g)
+        eng.grad_eri(D, hyb, g2, spin_density=M)
+        if mf._nranks > 1:
+            from . import parallel
+            parallel.all_reduce_sum(g2, mf._pg)
+        de = (g + g2).cpu().numpy() + grad_nuc(mol)
+        if is_ks:
+            de = de + self.grad_xc_spin(mf._dm)
+        if mf._nranks > 1:
+            from . import parallel
+            dt = torch.as_tensor(de, device=eng.device)
+            parallel.broadcast0(dt, mf._pg)
+            de = dt.cpu().numpy()
+        self.de = de
+        if self.verbose >= 4:
+            mf._log(4, "--------------- gradients ---------------")
+            for ia in range(mol.natm):
+                mf._log(4, "%d %s  %16.10f %16.10f %16.10f" % (ia, mol.atom_pure_symbol(ia), *de[ia]))
+        return de
+
+    grad = kernel
+
+
 class FDGradients:
     step = 2.0e-3  # Bohr
 

@@ -173,6 +173,9 @@ int mi_grad_1e(mi_ctx *ctx, const double *d_D, const double *d_W, double *d_grad
  * kernels [MEM] (mf.nuc_grad_method().get_jk).  On a sharded context the quartet batches are dealt
  * round-robin to ranks: the result is a partial sum to be all-reduced by the caller. */
 int mi_grad_eri(mi_ctx *ctx, const double *d_D, double hyb, double *d_grad, void *stream);
+/* Open-shell form (UHF/UKS, templates/calculate_bde.py:224 optimises radicals): d_D = Da + Db, d_Dspin = Da - Db
+ * (NULL: closed shell); the exchange part contracts sum_s Ds x Ds = (D x D + M x M) / 2. */
+int mi_grad_eri_spin(mi_ctx *ctx, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, void *stream);
 
 /* d_vmat[nao][nao] += ao0 . aow^T over the grid block (split-K FP64 MFMA kernel; rocBLAS has no split-K for
  * this tiny-M,N / huge-K shape and runs it at < 1 TFLOP/s).  The caller symmetrises (Vxc = vmat + vmat^T). */

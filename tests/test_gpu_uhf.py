@@ -54,3 +54,24 @@ def test_uhf_known_answers():
     e_u = scf.UHF(h2o).kernel()
     e_r = scf.RHF(h2o).kernel()
     assert abs(e_u - e_r) < 1e-8 and abs(e_r + 75.98394849812) < 1e-7   # PySCF test-suite value [MEM]
+
+
+def test_uhf_gradient_matches_finite_differences():
+    """Analytic UHF gradient (open-shell two-particle density in `mi_grad_eri_spin`) vs central differences of the
+    UHF energy; closed shell: UHF gradient == RHF gradient."""
+    from pyscf import scf
+    from mi355scf.grad import FDGradients
+    mol = _mol("O 0 0 0; H 0.1 0.05 0.97", "6-31G*", 1)
+    mf = scf.UHF(mol).to_gpu()
+    mf.conv_tol = 1e-11
+    mf.kernel()
+    g = mf.nuc_grad_method().kernel()
+    fd = FDGradients(mf)
+    fd.step = 5e-4
+    g_fd = fd.kernel()
+    assert np.abs(g - g_fd).max() < 2e-6
+    assert np.abs(g.sum(axis=0)).max() < 1e-8           # translational invariance
+    h2o = _mol("O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587", "6-31G*", 0)
+    gu = scf.UHF(h2o).nuc_grad_method().kernel()
+    gr = scf.RHF(h2o).nuc_grad_method().kernel()
+    assert np.abs(gu - gr).max() < 1e-6
