@@ -2137,91 +2137,200 @@ extern "C" int mi_xc_rho(mi_ctx *c, const double *d_ao, const double *d_C, int64
     return 0;
 }
 
-// ---- forward-mode dual numbers: value, d/drho, d/dsigma
-struct D2 {
-    double v, r, s;
-    __device__ D2() {}
-    __device__ D2(double a) : v(a), r(0), s(0) {}
-    __device__ D2(double a, double b, double c) : v(a), r(b), s(c) {}
+// ---- forward-mode dual numbers: value + N partial derivatives (N = 2: d/drho, d/dsigma of the closed-shell
+// functionals; N = 5: d/d(rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb) of the spin-polarised ones)
+template <int N>
+struct DN {
+    double v, d[N];
+    __device__ DN() {}
+    __device__ DN(double a) : v(a) {
+#pragma unroll
+        for (int i = 0; i < N; i++) d[i] = 0.0;
+    }
+    __device__ static DN var(double a, int which) { DN x(a); x.d[which] = 1.0; return x; }
 };
-__device__ inline D2 operator+(D2 a, D2 b) { return D2(a.v + b.v, a.r + b.r, a.s + b.s); }
-__device__ inline D2 operator-(D2 a, D2 b) { return D2(a.v - b.v, a.r - b.r, a.s - b.s); }
-__device__ inline D2 operator-(D2 a) { return D2(-a.v, -a.r, -a.s); }
-__device__ inline D2 operator*(D2 a, D2 b) { return D2(a.v * b.v, a.r * b.v + a.v * b.r, a.s * b.v + a.v * b.s); }
-__device__ inline D2 operator/(D2 a, D2 b)
-{
-    double iv = 1.0 / b.v, q = a.v * iv;
-    return D2(q, (a.r - q * b.r) * iv, (a.s - q * b.s) * iv);
-}
-__device__ inline D2 chain(D2 a, double f, double df) { return D2(f, df * a.r, df * a.s); }
-__device__ inline D2 dexp(D2 a) { double e = exp(a.v); return chain(a, e, e); }
-__device__ inline D2 dlog(D2 a) { return chain(a, log(a.v), 1.0 / a.v); }
-__device__ inline D2 dsqrt(D2 a) { double s = sqrt(a.v); return chain(a, s, 0.5 / s); }
-__device__ inline D2 dpow(D2 a, double p) { double f = pow(a.v, p); return chain(a, f, p * f / a.v); }
-__device__ inline D2 datan(D2 a) { return chain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
-__device__ inline D2 dasinh(D2 a) { return chain(a, asinh(a.v), rsqrt(1.0 + a.v * a.v)); }
+template <int N> __device__ inline DN<N> operator+(DN<N> a, DN<N> b) { DN<N> r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> __device__ inline DN<N> operator-(DN<N> a, DN<N> b) { DN<N> r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> __device__ inline DN<N> operator-(DN<N> a) { DN<N> r; r.v = -a.v;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = -a.d[i]; return r; }
+template <int N> __device__ inline DN<N> operator*(DN<N> a, DN<N> b) { DN<N> r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> __device__ inline DN<N> operator/(DN<N> a, DN<N> b) { DN<N> r; double iv = 1.0 / b.v, q = a.v * iv; r.v = q;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = (a.d[i] - q * b.d[i]) * iv; return r; }
+template <int N> __device__ inline DN<N> chain(DN<N> a, double f, double df) { DN<N> r; r.v = f;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = df * a.d[i]; return r; }
+template <int N> __device__ inline DN<N> dexp(DN<N> a) { double e = exp(a.v); return chain(a, e, e); }
+template <int N> __device__ inline DN<N> dlog(DN<N> a) { return chain(a, log(a.v), 1.0 / a.v); }
+template <int N> __device__ inline DN<N> dsqrt(DN<N> a) { double s = sqrt(a.v); return chain(a, s, 0.5 / s); }
+template <int N> __device__ inline DN<N> dpow(DN<N> a, double p) { double f = pow(a.v, p); return chain(a, f, p * f / a.v); }
+template <int N> __device__ inline DN<N> datan(DN<N> a) { return chain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+template <int N> __device__ inline DN<N> dasinh(DN<N> a) { return chain(a, asinh(a.v), rsqrt(1.0 + a.v * a.v)); }
+typedef DN<2> D2;
+typedef DN<5> D5;
 
 enum { XC_SLATER = 1, XC_B88 = 2, XC_VWN_RPA = 3, XC_VWN5 = 4, XC_LYP = 5, XC_PBE_X = 6, XC_PBE_C = 7 };
 
-__device__ inline D2 f_slater(D2 rho) { return D2(-0.7385587663820224) * dpow(rho, 4.0 / 3.0); } // -(3/4)(3/pi)^(1/3)
+// ---- closed-shell energy densities per volume e(rho, sigma); T is a dual-number type
+template <class T> __device__ inline T f_slater(T rho) { return T(-0.7385587663820224) * dpow(rho, 4.0 / 3.0); } // -(3/4)(3/pi)^(1/3)
 
-__device__ inline D2 f_b88(D2 rho, D2 sig)
+template <class T> __device__ inline T f_b88(T rho, T sig)
 {
     const double beta = 0.0042;
-    D2 rs = rho * D2(0.5);                 // one spin channel
-    D2 r43 = dpow(rs, 4.0 / 3.0);
-    D2 x = dsqrt(sig * D2(0.25) + D2(1e-300)) / r43;
-    D2 corr = D2(-beta) * r43 * x * x / (D2(1.0) + D2(6.0 * beta) * x * dasinh(x));
-    return f_slater(rho) + D2(2.0) * corr;
+    T rs = rho * T(0.5);                 // one spin channel
+    T r43 = dpow(rs, 4.0 / 3.0);
+    T x = dsqrt(sig * T(0.25) + T(1e-300)) / r43;
+    T corr = T(-beta) * r43 * x * x / (T(1.0) + T(6.0 * beta) * x * dasinh(x));
+    return f_slater(rho) + T(2.0) * corr;
 }
 
-__device__ inline D2 f_vwn(D2 rho, double A, double x0, double b, double c)
+// VWN fit: correlation energy per electron as a function of x = sqrt(rs)
+template <class T> __device__ inline T vwn_eps(T x, double A, double x0, double b, double c)
 {
-    D2 rs = dpow(D2(0.75 / M_PI) / rho, 1.0 / 3.0);
-    D2 x = dsqrt(rs);
-    D2 X = x * x + D2(b) * x + D2(c);
+    T X = x * x + T(b) * x + T(c);
     double X0 = x0 * x0 + b * x0 + c, Q = sqrt(4 * c - b * b);
-    D2 at = datan(D2(Q) / (D2(2.0) * x + D2(b)));
-    D2 xm = x - D2(x0);
-    D2 eps = D2(A) * (dlog(x * x / X) + D2(2 * b / Q) * at - D2(b * x0 / X0) * (dlog(xm * xm / X) + D2(2 * (b + 2 * x0) / Q) * at));
-    return rho * eps;
+    T at = datan(T(Q) / (T(2.0) * x + T(b)));
+    T xm = x - T(x0);
+    return T(A) * (dlog(x * x / X) + T(2 * b / Q) * at - T(b * x0 / X0) * (dlog(xm * xm / X) + T(2 * (b + 2 * x0) / Q) * at));
 }
 
-__device__ inline D2 f_lyp(D2 rho, D2 sig)
+template <class T> __device__ inline T f_vwn(T rho, double A, double x0, double b, double c)
+{
+    T rs = dpow(T(0.75 / M_PI) / rho, 1.0 / 3.0);
+    return rho * vwn_eps(dsqrt(rs), A, x0, b, c);
+}
+
+template <class T> __device__ inline T f_lyp(T rho, T sig)
 {
     const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349;
     const double CF = 2.871234000188191; // (3/10)(3 pi^2)^(2/3)
-    D2 t = dpow(rho, -1.0 / 3.0);
-    D2 Dn = D2(1.0) + D2(d) * t;
-    D2 om = dexp(D2(-c) * t) / Dn * dpow(rho, -11.0 / 3.0);
-    D2 dl = D2(c) * t + D2(d) * t / Dn;
-    D2 br = D2(CF) * dpow(rho, 14.0 / 3.0) - rho * rho * sig * (D2(1.0 / 24.0) + D2(7.0 / 72.0) * dl);
-    return D2(-a) * rho / Dn - D2(a * b) * om * br;
+    T t = dpow(rho, -1.0 / 3.0);
+    T Dn = T(1.0) + T(d) * t;
+    T om = dexp(T(-c) * t) / Dn * dpow(rho, -11.0 / 3.0);
+    T dl = T(c) * t + T(d) * t / Dn;
+    T br = T(CF) * dpow(rho, 14.0 / 3.0) - rho * rho * sig * (T(1.0 / 24.0) + T(7.0 / 72.0) * dl);
+    return T(-a) * rho / Dn - T(a * b) * om * br;
 }
 
-__device__ inline D2 f_pbe_x(D2 rho, D2 sig)
+template <class T> __device__ inline T f_pbe_x(T rho, T sig)
 {
     const double kappa = 0.804, mu = 0.06672455060314922 * M_PI * M_PI / 3.0;
-    D2 kf = dpow(D2(3.0 * M_PI * M_PI) * rho, 1.0 / 3.0);
-    D2 s2 = sig / (D2(4.0) * kf * kf * rho * rho);
-    D2 F = D2(1.0 + kappa) - D2(kappa) / (D2(1.0) + D2(mu / kappa) * s2);
+    T kf = dpow(T(3.0 * M_PI * M_PI) * rho, 1.0 / 3.0);
+    T s2 = sig / (T(4.0) * kf * kf * rho * rho);
+    T F = T(1.0 + kappa) - T(kappa) / (T(1.0) + T(mu / kappa) * s2);
     return f_slater(rho) * F;
 }
 
-__device__ inline D2 f_pbe_c(D2 rho, D2 sig)
+// PW92 form G(rs; A, a1, b1..b4) = -2A(1 + a1 rs) ln(1 + 1/(2A(b1 x + b2 x^2 + b3 x^3 + b4 x^4))), x = sqrt(rs)
+template <class T> __device__ inline T pw92_g(T rs, double A, double a1, double b1, double b2, double b3, double b4)
+{
+    T x = dsqrt(rs);
+    return T(-2 * A) * (T(1.0) + T(a1) * rs) * dlog(T(1.0) + T(1.0) / (T(2 * A) * (T(b1) * x + T(b2) * rs + T(b3) * rs * x + T(b4) * rs * rs)));
+}
+
+template <class T> __device__ inline T f_pbe_c(T rho, T sig)
 {
     const double beta = 0.06672455060314922, gamma = 0.031090690869654895;
-    const double A = 0.031090690869654895, a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
-    D2 rs = dpow(D2(0.75 / M_PI) / rho, 1.0 / 3.0);
-    D2 x = dsqrt(rs);
-    D2 ec = D2(-2 * A) * (D2(1.0) + D2(a1) * rs) *
-            dlog(D2(1.0) + D2(1.0) / (D2(2 * A) * (D2(b1) * x + D2(b2) * rs + D2(b3) * rs * x + D2(b4) * rs * rs)));
-    D2 kf = dpow(D2(3.0 * M_PI * M_PI) * rho, 1.0 / 3.0);
-    D2 ks2 = D2(4.0 / M_PI) * kf;
-    D2 t2 = sig / (D2(4.0) * ks2 * rho * rho);
-    D2 Aa = D2(beta / gamma) / (dexp(-ec / D2(gamma)) - D2(1.0));
-    D2 At2 = Aa * t2;
-    D2 H = D2(gamma) * dlog(D2(1.0) + D2(beta / gamma) * t2 * (D2(1.0) + At2) / (D2(1.0) + At2 + At2 * At2));
+    T rs = dpow(T(0.75 / M_PI) / rho, 1.0 / 3.0);
+    T ec = pw92_g(rs, 0.031090690869654895, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+    T kf = dpow(T(3.0 * M_PI * M_PI) * rho, 1.0 / 3.0);
+    T ks2 = T(4.0 / M_PI) * kf;
+    T t2 = sig / (T(4.0) * ks2 * rho * rho);
+    T Aa = T(beta / gamma) / (dexp(-ec / T(gamma)) - T(1.0));
+    T At2 = Aa * t2;
+    T H = T(gamma) * dlog(T(1.0) + T(beta / gamma) * t2 * (T(1.0) + At2) / (T(1.0) + At2 + At2 * At2));
+    return rho * (ec + H);
+}
+
+// ---- spin-polarised forms e(rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb)
+// exchange: spin scaling  E_x[ra, rb] = (E_x[2 ra] + E_x[2 rb]) / 2  with sigma -> 4 sigma_ss
+template <class T, class F> __device__ inline T spin_scaled_exchange(T ra, T rb, T saa, T sbb, F fx)
+{
+    T e(0.0);
+    if (ra.v > 1e-12) e = e + T(0.5) * fx(T(2.0) * ra, T(4.0) * saa);
+    if (rb.v > 1e-12) e = e + T(0.5) * fx(T(2.0) * rb, T(4.0) * sbb);
+    return e;
+}
+// zeta = (ra - rb)/rho clipped away from +-1 (the derivatives of (1 +- zeta)^(4/3) etc. stay finite)
+template <class T> __device__ inline T spin_zeta(T ra, T rb)
+{
+    T z = (ra - rb) / (ra + rb);
+    const double lim = 1.0 - 1e-10;
+    if (z.v > lim) z = T(lim);
+    if (z.v < -lim) z = T(-lim);
+    return z;
+}
+template <class T> __device__ inline T spin_fzeta(T z) // ((1+z)^(4/3) + (1-z)^(4/3) - 2) / (2^(4/3) - 2)
+{
+    return (dpow(T(1.0) + z, 4.0 / 3.0) + dpow(T(1.0) - z, 4.0 / 3.0) - T(2.0)) * T(1.0 / (2.5198420997897464 - 2.0));
+}
+// VWN-RPA (libxc LDA_C_VWN_RPA, the correlation of B3LYP): eps = eps_P + (eps_F - eps_P) f(zeta), RPA fits
+template <class T> __device__ inline T f_vwn_rpa_spin(T ra, T rb)
+{
+    T rho = ra + rb;
+    T x = dsqrt(dpow(T(0.75 / M_PI) / rho, 1.0 / 3.0));
+    T eP = vwn_eps(x, 0.0310907, -0.409286, 13.0720, 42.7198);
+    T eF = vwn_eps(x, 0.01554535, -0.743294, 20.1231, 101.578);
+    return rho * (eP + (eF - eP) * spin_fzeta(spin_zeta(ra, rb)));
+}
+// VWN5: eps = eps_P + alpha_c f(z)/f''(0) (1 - z^4) + (eps_F - eps_P) f(z) z^4
+template <class T> __device__ inline T f_vwn5_spin(T ra, T rb)
+{
+    T rho = ra + rb;
+    T x = dsqrt(dpow(T(0.75 / M_PI) / rho, 1.0 / 3.0));
+    T eP = vwn_eps(x, 0.0310907, -0.10498, 3.72744, 12.9352);
+    T eF = vwn_eps(x, 0.01554535, -0.32500, 7.06042, 18.0578);
+    T ac = vwn_eps(x, -1.0 / (6.0 * M_PI * M_PI), -0.0047584, 1.13107, 13.0045);
+    T z = spin_zeta(ra, rb), fz = spin_fzeta(z), z4 = z * z * z * z;
+    return rho * (eP + ac * fz * T(1.0 / 1.7099209341613657) * (T(1.0) - z4) + (eF - eP) * fz * z4);
+}
+// LYP, open-shell form of Miehlich, Savin, Stoll, Preuss, CPL 157, 200 (1989)
+template <class T> __device__ inline T f_lyp_spin(T ra, T rb, T saa, T sab, T sbb)
+{
+    const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349;
+    const double CF = 2.871234000188191;
+    T rho = ra + rb;
+    T sig = saa + T(2.0) * sab + sbb;
+    T t = dpow(rho, -1.0 / 3.0);
+    T Dn = T(1.0) + T(d) * t;
+    T om = dexp(T(-c) * t) / Dn * dpow(rho, -11.0 / 3.0);
+    T dl = T(c) * t + T(d) * t / Dn;
+    T rab = ra * rb;
+    T pa(0.0), pb(0.0);
+    if (ra.v > 1e-14) pa = dpow(ra, 8.0 / 3.0);
+    if (rb.v > 1e-14) pb = dpow(rb, 8.0 / 3.0);
+    T t1 = T(12.699208415745595 * CF) * (pa + pb) /* 2^(11/3) C_F */ + (T(47.0 / 18.0) - T(7.0 / 18.0) * dl) * sig -
+           (T(2.5) - dl * T(1.0 / 18.0)) * (saa + sbb) - (dl - T(11.0)) * T(1.0 / 9.0) * (ra / rho * saa + rb / rho * sbb);
+    T br = rab * t1 - T(2.0 / 3.0) * rho * rho * sig + (T(2.0 / 3.0) * rho * rho - ra * ra) * sbb + (T(2.0 / 3.0) * rho * rho - rb * rb) * saa;
+    return T(-4.0 * a) * rab / (Dn * rho) - T(a * b) * om * br;
+}
+// PBE correlation with the PW92 spin interpolation and phi(zeta)
+template <class T> __device__ inline T f_pbe_c_spin(T ra, T rb, T saa, T sab, T sbb)
+{
+    const double beta = 0.06672455060314922, gamma = 0.031090690869654895;
+    T rho = ra + rb;
+    T sig = saa + T(2.0) * sab + sbb;
+    T rs = dpow(T(0.75 / M_PI) / rho, 1.0 / 3.0);
+    T e0 = pw92_g(rs, 0.031090690869654895, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+    T e1 = pw92_g(rs, 0.015545345434827448, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+    T mac = pw92_g(rs, 0.016886863940389627, 0.11125, 10.357, 3.6231, 0.88026, 0.49671); // = -alpha_c
+    T z = spin_zeta(ra, rb), fz = spin_fzeta(z), z4 = z * z * z * z;
+    T ec = e0 - mac * fz * T(1.0 / 1.7099209341613657) * (T(1.0) - z4) + (e1 - e0) * fz * z4;
+    T phi = T(0.5) * (dpow(T(1.0) + z, 2.0 / 3.0) + dpow(T(1.0) - z, 2.0 / 3.0));
+    T phi3 = phi * phi * phi;
+    T kf = dpow(T(3.0 * M_PI * M_PI) * rho, 1.0 / 3.0);
+    T ks2 = T(4.0 / M_PI) * kf;
+    T t2 = sig / (T(4.0) * phi * phi * ks2 * rho * rho);
+    T Aa = T(beta / gamma) / (dexp(-ec / (T(gamma) * phi3)) - T(1.0));
+    T At2 = Aa * t2;
+    T H = T(gamma) * phi3 * dlog(T(1.0) + T(beta / gamma) * t2 * (T(1.0) + At2) / (T(1.0) + At2 + At2 * At2));
     return rho * (ec + H);
 }
 
@@ -2237,7 +2346,7 @@ __global__ __launch_bounds__(256) void xc_eval_kernel(XcSpec X, const double *rh
     double gx = gga ? rho[ng + g] : 0.0, gy = gga ? rho[2 * ng + g] : 0.0, gz = gga ? rho[3 * ng + g] : 0.0;
     double e = 0.0, vr = 0.0, vs = 0.0;
     if (r > 1e-10) {
-        D2 R(r, 1.0, 0.0), S(gx * gx + gy * gy + gz * gz, 0.0, 1.0);
+        D2 R = D2::var(r, 0), S = D2::var(gx * gx + gy * gy + gz * gz, 1);
         D2 acc(0.0);
         for (int t = 0; t < X.n; t++) {
             D2 f;
@@ -2253,7 +2362,7 @@ __global__ __launch_bounds__(256) void xc_eval_kernel(XcSpec X, const double *rh
             }
             acc = acc + D2(X.coef[t]) * f;
         }
-        e = acc.v; vr = acc.r; vs = acc.s;
+        e = acc.v; vr = acc.d[0]; vs = acc.d[1];
     }
     if (exc) exc[g] = e;
     if (vrho_out) vrho_out[g] = vr;
@@ -2266,6 +2375,68 @@ __global__ __launch_bounds__(256) void xc_eval_kernel(XcSpec X, const double *rh
             wv[ng + g] = f * gx; wv[2 * ng + g] = f * gy; wv[3 * ng + g] = f * gz;
         }
     }
+}
+
+// Spin-polarised evaluation (UKS): rho_s[0] = density, rho_s[1..3] = its gradient.  exc[g] = e per volume;
+// wv_s[0] = 0.5 w de/drho_s ; wv_s[1..3] = w (2 de/dsigma_ss grad rho_s + de/dsigma_ab grad rho_s')  (same consumer as the
+// closed-shell wv: V_s = ao^T aow_s + transpose)
+__global__ __launch_bounds__(256) void xc_eval_spin_kernel(XcSpec X, const double *rhoa, const double *rhob, const double *w, int64_t ng,
+                                                           int gga, double *exc, double *wva, double *wvb)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const double ra = fmax(rhoa[g], 0.0), rb = fmax(rhob[g], 0.0);
+    double ga[3] = {0, 0, 0}, gb[3] = {0, 0, 0};
+    if (gga)
+        for (int k = 0; k < 3; k++) { ga[k] = rhoa[(k + 1) * ng + g]; gb[k] = rhob[(k + 1) * ng + g]; }
+    double e = 0.0, v[5] = {0, 0, 0, 0, 0};
+    if (ra + rb > 1e-10) {
+        D5 Ra = D5::var(ra, 0), Rb = D5::var(rb, 1);
+        D5 Saa = D5::var(ga[0] * ga[0] + ga[1] * ga[1] + ga[2] * ga[2], 2);
+        D5 Sab = D5::var(ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2], 3);
+        D5 Sbb = D5::var(gb[0] * gb[0] + gb[1] * gb[1] + gb[2] * gb[2], 4);
+        D5 acc(0.0);
+        for (int t = 0; t < X.n; t++) {
+            D5 f(0.0);
+            switch (X.kind[t]) {
+            case XC_SLATER: f = spin_scaled_exchange(Ra, Rb, Saa, Sbb, [](D5 r, D5) { return f_slater(r); }); break;
+            case XC_B88: f = spin_scaled_exchange(Ra, Rb, Saa, Sbb, [](D5 r, D5 s_) { return f_b88(r, s_); }); break;
+            case XC_PBE_X: f = spin_scaled_exchange(Ra, Rb, Saa, Sbb, [](D5 r, D5 s_) { return f_pbe_x(r, s_); }); break;
+            case XC_VWN_RPA: f = f_vwn_rpa_spin(Ra, Rb); break;
+            case XC_VWN5: f = f_vwn5_spin(Ra, Rb); break;
+            case XC_LYP: f = f_lyp_spin(Ra, Rb, Saa, Sab, Sbb); break;
+            case XC_PBE_C: f = f_pbe_c_spin(Ra, Rb, Saa, Sab, Sbb); break;
+            default: break;
+            }
+            acc = acc + D5(X.coef[t]) * f;
+        }
+        e = acc.v;
+        for (int k = 0; k < 5; k++) v[k] = acc.d[k];
+    }
+    if (exc) exc[g] = e;
+    const double ww = w[g];
+    wva[g] = 0.5 * ww * v[0];
+    wvb[g] = 0.5 * ww * v[1];
+    if (gga)
+        for (int k = 0; k < 3; k++) {
+            wva[(k + 1) * ng + g] = ww * (2.0 * v[2] * ga[k] + v[3] * gb[k]);
+            wvb[(k + 1) * ng + g] = ww * (2.0 * v[4] * gb[k] + v[3] * ga[k]);
+        }
+}
+
+extern "C" int mi_xc_eval_spin(const int32_t *kinds, const double *coefs, int nterms, const double *d_rhoa, const double *d_rhob,
+                               const double *d_w, int64_t ng, int gga, double *d_exc, double *d_wva, double *d_wvb, void *stream)
+{
+    if (nterms < 0 || nterms > 8) return fail("mi_xc_eval_spin: at most 8 functional terms");
+    if (!d_rhoa || !d_rhob || !d_w || !d_wva || !d_wvb) return fail("mi_xc_eval_spin: null argument");
+    XcSpec X{};
+    X.n = nterms;
+    for (int i = 0; i < nterms; i++) { X.kind[i] = kinds[i]; X.coef[i] = coefs[i]; }
+    if (ng <= 0) return 0;
+    hipLaunchKernelGGL(xc_eval_spin_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, d_rhoa, d_rhob, d_w,
+                       ng, gga, d_exc, d_wva, d_wvb);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 extern "C" int mi_xc_eval(const int32_t *kinds, const double *coefs, int nterms, const double *d_rho, const double *d_w,

@@ -1,2 +1,3 @@
-from . import rks  # noqa: F401
+from . import rks, uks  # noqa: F401
 RKS = rks.RKS
+UKS = uks.UKS

@@ -67,6 +67,7 @@ def lib():
         L.mi_eval_ao.argtypes = [vp, vp, i64, ctypes.c_int, vp, vp]
         L.mi_xc_rho.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
         L.mi_xc_eval.argtypes = [ip, dp, ctypes.c_int, vp, vp, i64, ctypes.c_int, vp, vp, vp, vp, vp]
+        L.mi_xc_eval_spin.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, i64, ctypes.c_int, vp, vp, vp, vp]
         L.mi_xc_aow.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
         L.mi_xc_vmat.argtypes = [vp, vp, vp, i64, vp, vp]
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
@@ -224,6 +225,19 @@ class Engine:
         rho = self._new(4 if deriv else 1, ng)
         _check(lib().mi_xc_rho(self._h, ao.data_ptr(), C.data_ptr(), ng, int(deriv), rho.data_ptr(), self._stream()))
         return rho
+
+    def xc_eval_spin(self, terms, rhoa, rhob, weights, gga=True):
+        """Spin-polarised functionals: (exc[ng], wva[(1|4)][ng], wvb[(1|4)][ng])."""
+        ng = rhoa.shape[-1]
+        kinds = np.array([k for _c, k in terms], dtype=np.int32)
+        coefs = np.array([c for c, _k in terms], dtype=np.float64)
+        exc = self._new(ng)
+        wva = self._new(4 if gga else 1, ng)
+        wvb = self._new(4 if gga else 1, ng)
+        _check(lib().mi_xc_eval_spin(kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dp(coefs), len(kinds),
+                                     rhoa.data_ptr(), rhob.data_ptr(), weights.data_ptr(), ng, int(gga), exc.data_ptr(),
+                                     wva.data_ptr(), wvb.data_ptr(), self._stream()))
+        return exc, wva, wvb
 
     def xc_eval(self, terms, rho, weights, gga=True, want_raw=False):
         """terms: [(coef, kind_id)] -> (exc[ng], wv[(1|4)][ng]) (+ vrho, vsigma if want_raw)."""

@@ -169,6 +169,44 @@ class UGradients(Gradients):
 
     grad = kernel
 
+    def grad_xc_spin(self, dm):
+        """XC gradient of UKS: the restricted expression per spin with (D_s, wv_s) from the spin-polarised functional."""
+        from .dft import parse_xc
+        mf = self.base
+        eng = mf.engine
+        hyb, terms, gga = parse_xc(mf.xc)
+        n = eng.nao
+        coords, weights = mf.grids.coords, mf.grids.weights
+        lo, hi = mf._grid_range(coords.shape[0])
+        fmu = torch.zeros(n, 3, dtype=torch.float64, device=eng.device)
+        B = max(4096, mf.grid_block // 4)
+        pair = {(0, 0): 4, (0, 1): 5, (0, 2): 6, (1, 1): 7, (1, 2): 8, (2, 2): 9}
+        for p0 in range(lo, hi, B):
+            p1 = min(p0 + B, hi)
+            c, w = coords[p0:p1], weights[p0:p1]
+            ao = eng.eval_ao(c, deriv=2 if gga else 1)
+            Cs = [dm[s_] @ ao[0] for s_ in range(2)]
+            rho = [eng.xc_rho(ao, Cs[s_], deriv=1 if gga else 0) for s_ in range(2)]
+            _e, wva, wvb = eng.xc_eval_spin(terms, rho[0], rho[1], w, gga)
+            for s_, wv in ((0, wva), (1, wvb)):
+                C = Cs[s_]
+                T1 = 2.0 * wv[0] * C
+                if gga:
+                    for j in range(3):
+                        T1 += wv[1 + j] * (dm[s_] @ ao[1 + j])
+                    for k in range(3):
+                        t2 = sum(wv[1 + j] * ao[pair[(min(j, k), max(j, k))]] for j in range(3))
+                        fmu[:, k] += -2.0 * ((ao[1 + k] * T1).sum(dim=1) + (t2 * C).sum(dim=1))
+                else:
+                    for k in range(3):
+                        fmu[:, k] += -2.0 * (ao[1 + k] * T1).sum(dim=1)
+        if mf._nranks > 1:
+            from . import parallel
+            parallel.all_reduce_sum(fmu, mf._pg)
+        f = fmu.cpu().numpy()
+        sl = mf.mol.aoslice_by_atom()
+        return np.array([f[sl[ia, 2]:sl[ia, 3]].sum(axis=0) for ia in range(mf.mol.natm)])
+
 
 class FDGradients:
     step = 2.0e-3  # Bohr

@@ -1,0 +1,98 @@
+"""Spin-unrestricted Kohn-Sham behind `pyscf.dft.UKS` / `gpu4pyscf.dft.UKS` (call sites
+`templates/calculate_bde.py:128,140,197,215`: `mf = UKS(mol); mf.xc = method` for the radical fragments).
+
+Same grid, AO, density and V_xc HIP kernels as RKS; the functional is evaluated by `mi_xc_eval_spin` (forward-mode
+dual numbers over rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb: spin-scaled exchange, VWN/PW92 spin interpolation,
+open-shell LYP, PBE correlation with phi(zeta)).  Meta-GGAs (the template's default M06-2X) are not implemented.
+The grid is not pruned by density (PySCF's `small_rho_cutoff` step is RKS-only here).
+"""
+import numpy as np
+import torch
+
+from .dft import RKS, parse_xc
+from .grids import Grids
+from .uhf import UHF
+
+
+class UKS(UHF):
+    xc = "LDA,VWN"
+    grid_block = RKS.grid_block
+    cache_ao = True
+
+    def __init__(self, mol, xc=None):
+        UHF.__init__(self, mol)
+        if xc is not None:
+            self.xc = xc
+        self.grids = Grids(mol)
+        self._nelec_grid = None
+
+    def reset(self, mol=None):
+        UHF.reset(self, mol)
+        self.grids = Grids(self.mol)
+        lvl = getattr(self, "_grid_level", None)
+        if lvl is not None:
+            self.grids.level = lvl
+        return self
+
+    def _setup(self):
+        UHF._setup(self)
+        if self.grids.weights is None or self.grids.mol is not self.mol:
+            self.grids.mol = self.mol
+            self.grids.build(engine=self.engine)
+            self._log(4, f"XC grid: {self.grids.size} points (level {self.grids.level})")
+
+    _ao_cache_for = RKS._ao_cache_for
+    _grid_range = RKS._grid_range
+
+    def nr_uks(self, dm):
+        """((N_alpha, N_beta), E_xc, V_xc[2,N,N], hyb) on device for the spin densities dm[2,N,N] (numint.nr_uks [MEM])."""
+        eng = self.engine
+        hyb, terms, gga = parse_xc(self.xc)
+        n = eng.nao
+        coords, weights = self.grids.coords, self.grids.weights
+        ng = coords.shape[0]
+        vmat = torch.zeros(2, n, n, dtype=torch.float64, device=eng.device)
+        nelec = torch.zeros(2, dtype=torch.float64, device=eng.device)
+        exc = torch.zeros((), dtype=torch.float64, device=eng.device)
+        lo, hi = self._grid_range(ng)
+        B = max(self.grid_block, int(1.5e9 / (64.0 * n)) // 1024 * 1024)
+        cache = self._ao_cache_for(n, hi - lo, 4 if gga else 1)
+        for ib, p0 in enumerate(range(lo, hi, B)):
+            p1 = min(p0 + B, hi)
+            c, w = coords[p0:p1], weights[p0:p1]
+            if cache is not None and ib < len(cache):
+                ao = cache[ib]
+            else:
+                ao = eng.eval_ao(c, deriv=1 if gga else 0)
+                if cache is not None:
+                    cache.append(ao)
+            rho = [eng.xc_rho(ao, dm[s_] @ ao[0], deriv=1 if gga else 0) for s_ in range(2)]
+            e, wva, wvb = eng.xc_eval_spin(terms, rho[0], rho[1], w, gga)
+            nelec[0] += torch.dot(w, rho[0][0])
+            nelec[1] += torch.dot(w, rho[1][0])
+            exc += torch.dot(w, e)
+            for s_, wv in ((0, wva), (1, wvb)):
+                eng.xc_vmat(ao[0], eng.xc_aow(ao, wv, gga), vmat[s_])
+        vmat = vmat + vmat.transpose(1, 2)
+        return nelec, exc, vmat, hyb
+
+    def _fock_pair(self, dm):
+        nelec, exc, vxc, hyb = self.nr_uks(dm)
+        if self._nranks > 1:
+            from . import parallel
+            exc = exc.reshape(1)
+            parallel.all_reduce_fused([vxc, nelec, exc], self._pg)
+            exc = exc[0]
+        self._nelec_grid = nelec
+        h1 = self._h1.unsqueeze(0)
+        D = dm[0] + dm[1]
+        if abs(hyb) > 1e-12:
+            J, K = self._jk(dm)
+            Jt = J[0] + J[1]
+            F = h1 + Jt.unsqueeze(0) + vxc - hyb * K
+            e = torch.sum(D * self._h1) + 0.5 * torch.sum(D * Jt) - 0.5 * hyb * torch.sum(dm * K) + exc
+        else:
+            Jt = self._jk(D, with_k=False)[0]
+            F = h1 + Jt.unsqueeze(0) + vxc
+            e = torch.sum(D * self._h1) + 0.5 * torch.sum(D * Jt) + exc
+        return F, e

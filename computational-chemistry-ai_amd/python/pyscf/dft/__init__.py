@@ -1,4 +1,5 @@
-"""`pyscf.dft`: `RKS` (reference call sites `templates/calculate_energy.py:163,202`)."""
-from . import rks  # noqa: F401
+"""`pyscf.dft`: `RKS` (reference call sites `templates/calculate_energy.py:163,202`), `UKS` (`templates/calculate_bde.py:140`)."""
+from . import rks, uks  # noqa: F401
 RKS = rks.RKS
 KS = rks.RKS
+UKS = uks.UKS

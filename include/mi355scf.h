@@ -156,6 +156,10 @@ int mi_xc_rho(mi_ctx *ctx, const double *d_ao, const double *d_C, int64_t ng, in
 int mi_xc_eval(const int32_t *kinds, const double *coefs, int nterms, const double *d_rho,
                const double *d_w, int64_t ng, int gga, double *d_exc, double *d_wv, double *d_vrho,
                double *d_vsigma, void *stream);
+/* Spin-polarised form for UKS (reference call sites templates/calculate_bde.py:128,140,197,215): rho_s = [rho, grad rho]
+ * of spin s; wv_s feed mi_xc_aow / mi_xc_vmat exactly like the closed-shell wv and give V_xc of spin s. */
+int mi_xc_eval_spin(const int32_t *kinds, const double *coefs, int nterms, const double *d_rhoa, const double *d_rhob,
+                    const double *d_w, int64_t ng, int gga, double *d_exc, double *d_wva, double *d_wvb, void *stream);
 
 /* d_aow[nao][ng] = sum_c d_ao[c] * d_wv[c]; Vxc = ao0 @ aow^T + transpose is then one DGEMM. */
 int mi_xc_aow(mi_ctx *ctx, const double *d_ao, const double *d_wv, int64_t ng, int gga, double *d_aow,

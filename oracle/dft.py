@@ -346,3 +346,205 @@ def rks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-9, max_cycle=50, verbose
     r["nelec_grid"] = info.get("nelec")
     r["ngrids"] = info.get("ngrids", len(weights))
     return r
+
+
+# ---------------------------------------------------------------------------------------------
+# Spin-polarised functionals and UKS (checker for `mi355scf.uks.UKS`)
+# ---------------------------------------------------------------------------------------------
+def _vwn_eps(x, A, x0, b, c):
+    X = x * x + b * x + c
+    X0 = x0 * x0 + b * x0 + c
+    Q = np.sqrt(4 * c - b * b)
+    at = np.arctan(Q / (2 * x + b))
+    return A * (np.log(x * x / X) + 2 * b / Q * at - b * x0 / X0 * (np.log((x - x0) ** 2 / X) + 2 * (b + 2 * x0) / Q * at))
+
+
+def _fzeta(z):
+    return ((1 + z) ** (4.0 / 3) + (1 - z) ** (4.0 / 3) - 2) / (2 ** (4.0 / 3) - 2)
+
+
+_FPP0 = 4.0 / (9.0 * (2 ** (1.0 / 3) - 1))   # f''(0)
+
+
+def _zeta(ra, rb):
+    z = (ra - rb) / (ra + rb)
+    lim = 1.0 - 1e-10
+    return np.where(np.real(z) > lim, lim, np.where(np.real(z) < -lim, -lim, z))
+
+
+def _vwn_rpa_spin(ra, rb):
+    """libxc LDA_C_VWN_RPA [MEM]: eps_P + (eps_F - eps_P) f(zeta) with the RPA parameter sets."""
+    r = ra + rb
+    x = np.sqrt((3.0 / (4 * np.pi * r)) ** (1.0 / 3))
+    eP = _vwn_eps(x, 0.0310907, -0.409286, 13.0720, 42.7198)
+    eF = _vwn_eps(x, 0.01554535, -0.743294, 20.1231, 101.578)
+    return r * (eP + (eF - eP) * _fzeta(_zeta(ra, rb)))
+
+
+def _vwn5_spin(ra, rb):
+    """Vosko-Wilk-Nusair 1980, eq. 4.4 interpolation with the Ceperley-Alder fits (para, ferro, spin stiffness)."""
+    r = ra + rb
+    x = np.sqrt((3.0 / (4 * np.pi * r)) ** (1.0 / 3))
+    eP = _vwn_eps(x, 0.0310907, -0.10498, 3.72744, 12.9352)
+    eF = _vwn_eps(x, 0.01554535, -0.32500, 7.06042, 18.0578)
+    ac = _vwn_eps(x, -1.0 / (6 * np.pi ** 2), -0.0047584, 1.13107, 13.0045)
+    z = _zeta(ra, rb)
+    fz, z4 = _fzeta(z), z ** 4
+    return r * (eP + ac * fz / _FPP0 * (1 - z4) + (eF - eP) * fz * z4)
+
+
+def _pw92_g(rs, A, a1, b1, b2, b3, b4):
+    x = np.sqrt(rs)
+    return -2 * A * (1 + a1 * rs) * np.log(1 + 1 / (2 * A * (b1 * x + b2 * rs + b3 * rs * x + b4 * rs * rs)))
+
+
+def _pbe_c_spin(ra, rb, saa, sab, sbb):
+    """Perdew-Burke-Ernzerhof 1996 eqs. 3, 7, 8 with the Perdew-Wang 1992 spin interpolation (PW_MOD constants)."""
+    beta, gamma = 0.06672455060314922, (1 - np.log(2)) / np.pi ** 2
+    r = ra + rb
+    s = saa + 2 * sab + sbb
+    rs = (3.0 / (4 * np.pi * r)) ** (1.0 / 3)
+    e0 = _pw92_g(rs, 0.031090690869654895, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294)
+    e1 = _pw92_g(rs, 0.015545345434827448, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517)
+    mac = _pw92_g(rs, 0.016886863940389627, 0.11125, 10.357, 3.6231, 0.88026, 0.49671)
+    z = _zeta(ra, rb)
+    fz, z4 = _fzeta(z), z ** 4
+    ec = e0 - mac * fz / _FPP0 * (1 - z4) + (e1 - e0) * fz * z4
+    phi = 0.5 * ((1 + z) ** (2.0 / 3) + (1 - z) ** (2.0 / 3))
+    kf = (3 * np.pi ** 2 * r) ** (1.0 / 3)
+    ks2 = 4 * kf / np.pi
+    t2 = s / (4 * phi ** 2 * ks2 * r * r)
+    Aa = beta / gamma / (np.exp(-ec / (gamma * phi ** 3)) - 1)
+    H = gamma * phi ** 3 * np.log(1 + beta / gamma * t2 * (1 + Aa * t2) / (1 + Aa * t2 + Aa * Aa * t2 * t2))
+    return r * (ec + H)
+
+
+def energy_density_spin(terms, ra, rb, saa, sab, sbb):
+    """e(rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb) per volume; complex-safe.  Exchange by spin scaling."""
+    tiny = 1e-300
+    e = 0.0
+    for coef, kind in terms:
+        if kind == "slater":
+            e = e + coef * _slater(ra, rb)
+        elif kind == "b88":
+            # per spin channel; an empty channel contributes nothing (evaluated at a dummy density and masked)
+            for r_, s_ in ((ra, saa), (rb, sbb)):
+                ok = np.real(r_) > 1e-20
+                one = _b88(np.where(ok, r_, 1.0), 0.0 * r_ + 1.0, np.where(ok, s_, 0.0), 0.0 * s_) - _slater(0.0 * r_, 0.0 * r_ + 1.0)
+                e = e + coef * np.where(ok, one, 0.0)
+        elif kind == "vwn_rpa":
+            e = e + coef * _vwn_rpa_spin(ra, rb)
+        elif kind == "vwn5":
+            e = e + coef * _vwn5_spin(ra, rb)
+        elif kind == "lyp":
+            e = e + coef * _lyp(ra, rb, saa, sab, sbb)
+        elif kind == "pbe_x":
+            for r_, s_ in ((ra, saa), (rb, sbb)):
+                ok = np.real(r_) > 1e-20
+                e = e + coef * np.where(ok, 0.5 * _pbe_x(2 * np.where(ok, r_, 1.0), 4 * np.where(ok, s_, 0.0)), 0.0)
+        elif kind == "pbe_c":
+            e = e + coef * _pbe_c_spin(ra, rb, saa, sab, sbb)
+        else:
+            raise KeyError(kind)
+    return e
+
+
+def eval_xc_spin(terms, ra, rb, saa, sab, sbb):
+    """-> (e per volume, [de/dra, de/drb, de/dsaa, de/dsab, de/dsbb]) with complex-step derivatives."""
+    h = 1e-30
+    args = [np.asarray(a, dtype=complex) for a in (ra, rb, saa, sab, sbb)]
+    e = np.real(energy_density_spin(terms, *args))
+    ders = []
+    for i in range(5):
+        a2 = [a.copy() for a in args]
+        a2[i] = a2[i] + 1j * h
+        ders.append(np.imag(energy_density_spin(terms, *a2)) / h)
+    return e, ders
+
+
+def nr_uks(mol, coords, weights, xc, dm, block=20000, rho_cut=1e-10):
+    """(N_alpha, N_beta), E_xc, (V_a, V_b), hyb for the spin densities dm[2,N,N]."""
+    hyb, terms = parse_xc(xc)
+    nao = mol.nao
+    nel = np.zeros(2)
+    exc = 0.0
+    vmat = np.zeros((2, nao, nao))
+    for p0 in range(0, len(coords), block):
+        c, w = coords[p0:p0 + block], weights[p0:p0 + block]
+        ao = eval_ao(mol, c, 1)
+        rho, grad = [], []
+        for s_ in range(2):
+            c0 = ao[0] @ dm[s_]
+            rho.append(np.maximum(np.einsum("gi,gi->g", ao[0], c0), 0.0))
+            grad.append(np.array([2 * np.einsum("gi,gi->g", ao[1 + k], c0) for k in range(3)]))
+        ok = rho[0] + rho[1] > rho_cut
+        ra, rb = np.where(ok, rho[0], 0.5), np.where(ok, rho[1], 0.5)
+        saa = np.where(ok, (grad[0] * grad[0]).sum(axis=0), 0.0)
+        sab = np.where(ok, (grad[0] * grad[1]).sum(axis=0), 0.0)
+        sbb = np.where(ok, (grad[1] * grad[1]).sum(axis=0), 0.0)
+        e, d = eval_xc_spin(terms, ra, rb, saa, sab, sbb)
+        e = np.where(ok, e, 0.0)
+        d = [np.where(ok, x, 0.0) for x in d]
+        nel += [float(w @ rho[0]), float(w @ rho[1])]
+        exc += float(w @ e)
+        for s_, (vr, vss, g_own, g_oth) in enumerate(((d[0], d[2], grad[0], grad[1]), (d[1], d[4], grad[1], grad[0]))):
+            aow = ao[0] * (0.5 * w * vr)[:, None]
+            for k in range(3):
+                aow += ao[1 + k] * (w * (2 * vss * g_own[k] + d[3] * g_oth[k]))[:, None]
+            m = ao[0].T @ aow
+            vmat[s_] += m + m.T
+    return nel, exc, vmat, hyb
+
+
+def uks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-10, max_cycle=100, verbose=False):
+    """Spin-unrestricted Kohn-Sham on the oracle integrals and grid (no small-rho pruning).  dm0 as in oracle.uhf."""
+    coords, weights = build_grids(mol, level)
+    o = orc.Oracle(mol)
+    S, T, V, _ = o.int1e()
+    h = T + V
+    na, nb = mol.nelec
+    enuc = mol.energy_nuc()
+    info = {}
+
+    def dens(F):
+        out = []
+        for s_, no in ((0, na), (1, nb)):
+            e, c = orc.eig_gen(F[s_], S)
+            out.append(c[:, :no] @ c[:, :no].T)
+        return np.stack(out)
+
+    def fock(dm):
+        nel, exc, vxc, hyb = nr_uks(mol, coords, weights, xc, dm)
+        info["nelec"] = nel
+        Ja, Ka = o.jk(dm[0], tol=0.0)
+        Jb, Kb = o.jk(dm[1], tol=0.0)
+        J = Ja + Jb
+        F = np.stack([h + J + vxc[0] - hyb * Ka, h + J + vxc[1] - hyb * Kb])
+        D = dm[0] + dm[1]
+        e = float(np.sum(D * h)) + 0.5 * float(np.sum(D * J)) - 0.5 * hyb * float(np.sum(dm[0] * Ka) + np.sum(dm[1] * Kb)) + exc
+        return F, e + enuc
+
+    dm0 = np.asarray(dm0)
+    dm = dm0 if dm0.ndim == 3 else np.stack([dm0 * na / max(na + nb, 1), dm0 * nb / max(na + nb, 1)])
+    F, e = fock(dm)
+    Fh, Eh = [], []
+    for it in range(max_cycle):
+        err = np.stack([F[s_] @ dm[s_] @ S - S @ dm[s_] @ F[s_] for s_ in range(2)])
+        Fh.append(F.copy()); Eh.append(err.ravel().copy())
+        Fh, Eh = Fh[-8:], Eh[-8:]
+        m = len(Fh)
+        A = np.zeros((m + 1, m + 1)); A[0, 1:] = A[1:, 0] = 1.0
+        A[1:, 1:] = np.array([[a @ b for b in Eh] for a in Eh])
+        rhs = np.zeros(m + 1); rhs[0] = 1.0
+        c = np.linalg.lstsq(A, rhs, rcond=None)[0]
+        dm = dens(sum(ci * Fi for ci, Fi in zip(c[1:], Fh)))
+        F, e_new = fock(dm)
+        if verbose:
+            print(f"oracle uks cycle {it + 1}: E = {e_new:.12f}  dE = {e_new - e:.3e}")
+        done = abs(e_new - e) < conv_tol and np.abs(err).max() < 1e-6
+        e = e_new
+        if done:
+            break
+    dm = dens(F)
+    F, e = fock(dm)
+    return {"e_tot": e, "dm": dm, "nelec_grid": info["nelec"], "ngrids": len(weights)}

@@ -159,3 +159,36 @@ def test_literature_rhf_energies_pin_the_remembered_tz_tables(formula, basis, e_
         atom = f"C 0 0 0; H {a} {a} {a}; H {-a} {-a} {a}; H {-a} {a} {-a}; H {a} {-a} {-a}"
     res = orc.rhf(_mol(atom, basis))
     assert res["converged"] and abs(res["e_tot"] - e_lit) < tol, res["e_tot"]
+
+
+def test_oracle_uhf_and_spin_functionals_known_answers():
+    """Open-shell checkers: H atom UHF energies (exact in the basis: STO-3G -0.46658185, cc-pVDZ -0.49927840 [MEM]);
+    UHF == RHF for a closed shell; spin-polarised functionals reduce to the closed-shell forms at zeta = 0, LYP vanishes
+    for a fully polarised density, and the PW92 / VWN5 uniform-gas energies match the tabulated values
+    (PW92 Table: rs=1: -0.0598 / -0.0316, rs=2: -0.0448 / -0.0239 Ha for zeta = 0 / 1 [MEM])."""
+    import numpy as np
+    from mi355scf.mole import Mole
+    from oracle import oracle as orc
+    from oracle import dft as od
+    for basis, ref in (("sto-3g", -0.46658185), ("cc-pvdz", -0.49927840)):
+        m = Mole(atom="H 0 0 0", basis=basis, spin=1, verbose=0).build()
+        assert abs(orc.uhf(m)[0] - ref) < 2e-8
+    m = Mole(atom="O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587", basis="6-31g", verbose=0).build()
+    assert abs(orc.uhf(m)[0] - orc.rhf(m)["e_tot"]) < 1e-8
+    rng = np.random.default_rng(0)
+    rho = rng.uniform(0.01, 2.0, 64)
+    sig = rng.uniform(0, 1.0, 64) * rho ** 2
+    for name in ("B3LYP", "PBE", "LDA", "BLYP"):
+        _h, terms = od.parse_xc(name)
+        e0, vr, vs = od.eval_xc(terms, rho, sig)
+        e1, d = od.eval_xc_spin(terms, rho / 2, rho / 2, sig / 4, sig / 4, sig / 4)
+        assert np.abs(e0 - e1).max() < 1e-13 and np.abs(vr - d[0]).max() < 1e-12 and np.abs(vr - d[1]).max() < 1e-12
+        assert np.abs(4 * vs - (d[2] + d[3] + d[4])).max() < 1e-11   # d/dsigma = (d_aa + d_ab + d_bb)/4 at zeta = 0
+    e, _d = od.eval_xc_spin([(1.0, "lyp")], rho, 0 * rho, sig, 0 * rho, 0 * rho)
+    assert np.abs(e).max() < 1e-14
+    for rs, para, ferro in ((1.0, -0.0598, -0.0316), (2.0, -0.0448, -0.0239)):
+        r = 3 / (4 * np.pi * rs ** 3)
+        for fn in (od._pbe_c_spin, lambda a, b, *s: od._vwn5_spin(a, b)):
+            e_p = np.real(fn(np.array([r / 2 + 0j]), np.array([r / 2 + 0j]), 0, 0, 0))[0] / r
+            e_f = np.real(fn(np.array([r * (1 - 1e-12) + 0j]), np.array([r * 1e-12 + 0j]), 0, 0, 0))[0] / r
+            assert abs(e_p - para) < 4e-4 and abs(e_f - ferro) < 4e-4
