@@ -106,3 +106,50 @@ def test_optimize_geometry_flow():
     assert opt_coords.shape == (3, 3)
     roh = np.linalg.norm(opt_coords[0] - opt_coords[1])
     assert 0.93 < roh < 0.97      # RHF/6-31G water r(OH) ~0.95 A
+
+
+def test_bde_template_call_sequence_methane():
+    """The call sequence of `templates/calculate_bde.py:181-236` (gpu4pyscf.dft.RKS / UKS by `spin`, `mf.xc = method`,
+    `conv_tol = 1e-6`, `max_cycle = 100`, `optimize(mf, maxsteps=100)`, `mf.__class__(mol_eq)`, `mf_opt.xc = mf.xc`) for
+    CH4 -> CH3 + H with B3LYP/6-31G(d) (the template's default M06-2X is a meta-GGA and stays out of scope)."""
+    import gpu4pyscf
+    from pyscf import gto
+    from pyscf.geomopt.geometric_solver import optimize
+
+    def create_pyscf_mol(atoms, coords, basis, charge=0, spin=0):   # calculate_bde.py:77-103
+        mol = gto.Mole()
+        mol.atom = [[a, tuple(c)] for a, c in zip(atoms, coords)]
+        mol.basis, mol.charge, mol.spin, mol.verbose = basis, charge, spin, 0
+        mol.build()
+        return mol
+
+    def optimize_fragment(atoms, coords, spin):
+        mol = create_pyscf_mol(atoms, coords, "6-31G(d)", 0, spin)
+        mf = (gpu4pyscf.dft.RKS(mol) if spin == 0 else gpu4pyscf.dft.UKS(mol)).to_gpu()
+        mf.xc = "B3LYP"
+        mf.verbose = 0
+        mf.conv_tol = 1e-6
+        mf.max_cycle = 100
+        mol_eq = optimize(mf, maxsteps=100)
+        mf_opt = mf.__class__(mol_eq)
+        if hasattr(mf, "xc"):
+            mf_opt.xc = mf.xc
+        mf_opt.verbose = 0
+        return mol_eq.atom_coords(), mf_opt.kernel(), mf_opt
+
+    t = 0.629
+    ch4 = [(0, 0, 0), (t, t, t), (-t, -t, t), (-t, t, -t), (t, -t, -t)]
+    _, e_ch4, mf4 = optimize_fragment(["C", "H", "H", "H", "H"], ch4, 0)
+    xyz3, e_ch3, mf3 = optimize_fragment(["C", "H", "H", "H"], ch4[:4], 1)
+    mol_h = create_pyscf_mol(["H"], [(0, 0, 0)], "6-31G(d)", 0, 1)
+    mf_h = gpu4pyscf.dft.UKS(mol_h).to_gpu()
+    mf_h.xc = "B3LYP"
+    e_h = mf_h.kernel()
+    assert mf4.converged and mf3.converged and mf_h.converged
+    bde = e_ch3 + e_h - e_ch4
+    assert 0.165 < bde < 0.190, bde            # electronic C-H dissociation energy of methane ~ 0.178 Ha (112 kcal/mol)
+    # the methyl radical relaxes to a planar D3h structure: the carbon sits in the plane of the three hydrogens
+    c, h1, h2, h3 = xyz3
+    nrm = np.cross(h2 - h1, h3 - h1)
+    assert abs(np.dot(c - h1, nrm / np.linalg.norm(nrm))) < 0.02
+    assert abs(mf3.spin_square()[0] - 0.75) < 0.02
