@@ -153,7 +153,14 @@ def main():
                     continue  # already the headline roofline object
                 t = engine.time_jk_kernel(dm, reps=30, with_j=wj, with_k=wk)
                 b = 8.0 * est["n_unique_eri"] + 8.0 * nmat * nao * nao
-                more.append({"workload": label, "variant": name, "ms_per_launch": t, "algorithmic_bytes": b,
+                tr = None
+                try:
+                    case_ = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_jk_traffic.json")))["cases"].get(label)
+                    if case_ and wk and abs(case_["algorithmic_bytes"] - b) < 1e-6 * b:
+                        tr = case_["traffic_bytes"]   # committed rocprofv3 PMC passes (J+K kernel), see profiles/README.md
+                except Exception:
+                    tr = None
+                more.append({"workload": label, "variant": name, "ms_per_launch": t, "algorithmic_bytes": b, "traffic": tr,
                              "achieved": b / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, "stored_bytes": est["stored_bytes"]})
         leg(mf.engine, n, stats, st["dm"], args.molecule + "/" + args.basis)
