@@ -21,7 +21,9 @@ atom = {"benzene": lambda: fixtures.BENZENE, "ibuprofen": lambda: _atoms("CC(C)C
 mol = Mole(atom=atom, basis=basis, verbose=0).build()
 eng = Engine(mol)
 for rep in range(2):   # second pass reuses the parked tile store: no allocation
-    t0 = time.time(); st = eng.prepare_eri(1e-13); torch.cuda.synchronize()
+    sh = [a for a in sys.argv if a.startswith("--shard=")]
+    r_, n_ = (int(x) for x in sh[0].split("=")[1].split("/")) if sh else (0, 1)
+    t0 = time.time(); st = eng.prepare_eri(1e-13, r_, n_); torch.cuda.synchronize()
     print(json.dumps(dict(pass_=rep, prepare_s=round(time.time() - t0, 3), quartets=st["n_quartets"], resident_GB=st["stored_bytes"] / 1e9)), flush=True)
 if "--grad" in sys.argv:   # derivative-ERI contraction with a converged RHF density (realistic density-weighted screening)
     from mi355scf.scf import RHF
