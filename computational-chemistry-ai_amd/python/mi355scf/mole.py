@@ -211,6 +211,18 @@ class Mole:
             c = c * BOHR
         return c
 
+    def atom_mass_list(self, isotope_avg=False):
+        """Atomic masses in amu: isotope-averaged standard weights or the most abundant isotope (PySCF default) [MEM]."""
+        avg = {1: 1.008, 2: 4.002602, 3: 6.94, 4: 9.0121831, 5: 10.81, 6: 12.011, 7: 14.007, 8: 15.999, 9: 18.998403163,
+               10: 20.1797, 11: 22.98976928, 12: 24.305, 13: 26.9815385, 14: 28.085, 15: 30.973761998, 16: 32.06,
+               17: 35.45, 18: 39.948}
+        main = {1: 1.00782503223, 2: 4.00260325413, 3: 7.0160034366, 4: 9.012183065, 5: 11.00930536, 6: 12.0,
+                7: 14.00307400443, 8: 15.99491461957, 9: 18.99840316273, 10: 19.9924401762, 11: 22.989769282,
+                12: 23.985041697, 13: 26.98153853, 14: 27.97692653465, 15: 30.97376199842, 16: 31.9720711744,
+                17: 34.968852682, 18: 39.9623831237}
+        tab = avg if isotope_avg else main
+        return np.array([tab[int(z)] for z in self.atom_charges()])
+
     def atom_charges(self):
         return self._atm[:, CHARGE_OF].astype(np.int64).copy()
 

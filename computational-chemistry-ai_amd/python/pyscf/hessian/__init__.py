@@ -1,5 +1,8 @@
-"""Name-only module: `templates/optimize_geometry.py:15` imports `hessian`; the `--freq` branch
-(`:112-154`) is out of scope."""
-def _unsupported(*a, **k):
-    raise NotImplementedError("analytic Hessians are outside the MI355X Fock-build hot path")
-RHF = RKS = _unsupported
+"""`pyscf.hessian`: `RHF`, `RKS`, `UHF`, `UKS` factories, modules `rhf`/`rks`/`uhf`/`uks` with `Hessian`, and `thermo`
+(call sites `templates/optimize_geometry.py:15,117-147`, `templates/opt-freq.py:15,387-417,458,499`).  Semi-numerical:
+finite differences of the analytic HIP gradient (`mi355scf/hessian.py`)."""
+from . import rhf, rks, uhf, uks, thermo  # noqa: F401
+RHF = rhf.Hessian
+RKS = rks.Hessian
+UHF = uhf.Hessian
+UKS = uks.Hessian

@@ -1,0 +1,1 @@
+from mi355scf.hessian import Hessian  # noqa: F401

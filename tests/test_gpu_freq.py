@@ -1,0 +1,73 @@
+"""Vibrational analysis (call sites `templates/optimize_geometry.py:112-147`,
+`templates/opt-freq.py:387-417,458,499-506`): semi-numerical Hessian from the analytic HIP gradient, harmonic analysis and
+RRHO thermochemistry.  Checked against second differences of the ENERGY, rigid-body invariances, and the experimental-scale
+sanity of water's RHF/6-31G(d) frequencies (literature HF/6-31G(d): 1827, 4070, 4189 cm-1 [MEM], +-1 %)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_water_hessian_frequencies_and_thermo():
+    from pyscf import gto, scf, hessian
+    from pyscf.hessian import thermo
+    from pyscf.geomopt.geometric_solver import optimize
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.verbose = "O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587", "6-31G(d)", 0
+    mol.build()
+    mf = scf.RHF(mol).to_gpu()
+    mol_eq = optimize(mf, maxsteps=50)
+    mf = scf.RHF(mol_eq)
+    mf.conv_tol = 1e-11
+    mf.kernel()
+    h = hessian.RHF(mf)                       # optimize_geometry.py:117-118
+    hess = h.kernel()
+    n = mol_eq.natm
+    assert hess.shape == (n, n, 3, 3)
+    H = hess.transpose(0, 2, 1, 3).reshape(3 * n, 3 * n)
+    assert np.abs(H - H.T).max() < 1e-10
+    # translational invariance: sum over atoms of each row block vanishes
+    assert np.abs(hess.sum(axis=1)).max() < 2e-5
+    # one diagonal element against a second difference of the SCF energy
+    R = mol_eq.atom_coords()
+    d = 1e-2
+    es = []
+    for s in (-1, 0, 1):
+        Rd = R.copy(); Rd[0, 2] += s * d
+        m2 = mol_eq.set_geom_(Rd, unit="Bohr", inplace=False); m2.verbose = 0
+        f2 = scf.RHF(m2); f2.conv_tol = 1e-12
+        es.append(f2.kernel())
+    assert abs((es[0] - 2 * es[1] + es[2]) / d ** 2 - hess[0, 0, 2, 2]) < 2e-4
+    info = thermo.harmonic_analysis(mf.mol, hess)      # optimize_geometry.py:125
+    freq = info["freq_wavenumber"]
+    assert len(freq) == 3 and np.all(freq > 0)
+    for got, ref in zip(freq, (1827.0, 4070.0, 4189.0)):
+        assert abs(got - ref) < 0.012 * ref, freq
+    assert info["norm_mode"].shape == (3, n, 3)
+    res = thermo.thermo(mf, info["freq_au"], 298.15, 101325)    # opt-freq.py:499
+    zpe = res["ZPE"][0]
+    assert abs(zpe - 0.5 * info["freq_au"].sum()) < 1e-12 and 0.020 < zpe < 0.026
+    assert res["sym_number"][0] == 2
+    assert abs(res["H_tot"][0] - (res["E_tot"][0] + 298.15 * 3.166811563e-6)) < 1e-9
+    s_cal = res["S_tot"][0] * 627.509 * 1000.0
+    assert 44.0 < s_cal < 46.5                 # experimental S(H2O, g, 298 K) = 45.1 cal/mol/K
+    assert abs(res["G_tot"][0] - (res["H_tot"][0] - 298.15 * res["S_tot"][0])) < 1e-12
+
+
+def test_gpu4pyscf_hessian_surface_rks():
+    """`gpu_hessian.rks.Hessian(mf_opt).kernel()` (opt-freq.py:392-395) on H2 B3LYP: one stretching mode."""
+    import gpu4pyscf
+    from gpu4pyscf import hessian as gpu_hessian
+    from pyscf import gto, hessian
+    from pyscf.hessian import thermo
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.verbose = "H 0 0 0; H 0 0 0.743", "6-31G(d,p)", 0
+    mol.build()
+    mf = gpu4pyscf.dft.RKS(mol).to_gpu()
+    mf.xc = "B3LYP"
+    mf.kernel()
+    hess = gpu_hessian.rks.Hessian(mf).kernel()
+    assert hessian.rks.Hessian is gpu_hessian.rks.Hessian
+    info = thermo.harmonic_analysis(mol, hess)
+    assert info["rotor_type"] == "LINEAR" and len(info["freq_wavenumber"]) == 1
+    assert 4300.0 < info["freq_wavenumber"][0] < 4600.0      # B3LYP H2 stretch ~ 4450 cm-1

@@ -167,3 +167,33 @@ def test_optimizers_reach_the_same_minimum_on_a_model_surface():
     assert abs(energy(m1.atom_coords()) - energy(m2.atom_coords())) < 2e-6
     co2 = Mole(atom="O 0 0 -1.16; C 0 0 0; O 0 0 1.16", basis="sto-3g", verbose=0).build()
     assert geomopt.optimize_internal(energy_grad, co2, 5) is None
+
+
+def test_thermo_symmetry_numbers_and_diatomic_model():
+    """`pyscf.hessian.thermo` host logic: rotational symmetry numbers by brute-force rotation search, harmonic analysis of
+    a model diatomic Hessian (omega = sqrt(k/mu)), RRHO identities."""
+    from pyscf.hessian import thermo
+    from mi355scf import fixtures
+    from mi355scf.mole import Mole
+    cases = (("O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587", 2), (fixtures.BENZENE, 12),
+             ("C 0 0 0; H 0.629 0.629 0.629; H -0.629 -0.629 0.629; H -0.629 0.629 -0.629; H 0.629 -0.629 -0.629", 12),
+             ("N 0 0 0.1; H 0.94 0 -0.27; H -0.47 0.814 -0.27; H -0.47 -0.814 -0.27", 3),
+             ("O 0 0 -1.16; C 0 0 0; O 0 0 1.16", 2), ("H 0 0 0; F 0 0 0.92", 1))
+    for atom, sigma in cases:
+        assert thermo.rotational_symmetry_number(Mole(atom=atom, basis="sto-3g", verbose=0).build()) == sigma
+    m = Mole(atom="H 0 0 0; F 0 0 0.92", basis="sto-3g", verbose=0).build()
+    k = 0.62
+    H = np.zeros((2, 2, 3, 3))
+    H[0, 0, 2, 2] = H[1, 1, 2, 2] = k
+    H[0, 1, 2, 2] = H[1, 0, 2, 2] = -k
+    info = thermo.harmonic_analysis(m, H)
+    m1, m2 = m.atom_mass_list()
+    mu = m1 * m2 / (m1 + m2) * 1822.888486209
+    assert info["rotor_type"] == "LINEAR" and len(info["freq_au"]) == 1
+    assert abs(info["freq_au"][0] - np.sqrt(k / mu)) < 1e-9
+    assert abs(info["freq_wavenumber"][0] - np.sqrt(k / mu) * 219474.6313632) < 1e-3
+    res = thermo.thermo(m, info["freq_au"], 298.15, 101325)
+    assert abs(res["ZPE"][0] - 0.5 * info["freq_au"][0]) < 1e-14
+    assert abs(res["G_tot"][0] - (res["H_tot"][0] - 298.15 * res["S_tot"][0])) < 1e-15
+    # Sackur-Tetrode check: S_trans of a 20.006 amu ideal gas at 298.15 K, 1 atm = 34.9 cal/mol/K (HF: 34.96)
+    assert abs(res["S_trans"][0] * 627.509474 * 1000 - 34.94) < 0.1
