@@ -47,3 +47,27 @@ def test_optimize_geometry_template_imports_and_builds_mol():
     assert (mol.nelectron, mol.nao) == (112, 573)                # BASELINE config 5
     assert mol.atom_coords().shape == (33, 3)
     assert callable(mod.optimize)
+
+
+def test_calculate_bde_template_imports_enumerates_bonds_and_fragments():
+    """`templates/calculate_bde.py` imports unchanged; its RDKit-side helpers run on the
+    stand-in: bond enumeration, homolytic fragmentation into two radicals with coordinates, open-shell `Mole`s."""
+    mod = _load("calculate_bde")
+    bonds, rd = mod.get_all_bonds("CCO")
+    assert len(bonds) == 8 and rd.GetNumAtoms() == 9
+    kinds = {(a, b) for _i, _j, _t, a, b in bonds}
+    assert kinds == {("C", "C"), ("C", "H"), ("C", "O"), ("O", "H")}
+    i, j = next((i, j) for i, j, _t, a, b in bonds if (a, b) == ("C", "C"))
+    a1, c1, a2, c2 = mod.create_radical_fragments("CCO", i, j)
+    assert sorted(a1) == ["C", "H", "H", "H"] and sorted(a2) == sorted(["C", "O", "H", "H", "H"])
+    assert c1.shape == (4, 3) and c2.shape == (5, 3)
+    atoms, coords = mod.smiles_to_xyz("CCO")
+    # fragment coordinates are the parent's coordinates of the same atoms (the `_FromAtomIdx` path of the template)
+    assert any(np.allclose(c1[0], coords[k]) for k in range(len(atoms)))
+    m1 = mod.create_pyscf_mol(a1, c1, "6-31G(d)", charge=0, spin=1)       # methyl radical
+    m2 = mod.create_pyscf_mol(a2, c2, "6-31G(d)", charge=0, spin=1)       # CH2OH radical
+    assert m1.nelectron == 9 and m1.spin == 1 and m2.nelectron == 17
+    from pyscf import scf, dft
+    assert scf.UHF.__name__ == "UHF" and dft.UKS.__name__ == "UKS"
+    ring = mod.get_all_bonds("c1ccccc1")[0]
+    assert sum(1 for b in ring if b[2] == "AROMATIC") == 6
