@@ -16,35 +16,43 @@ from .scf import SCF
 
 
 class PairDIIS:
-    """Pulay CDIIS on stacked [2, N, N] Fock/error matrices (device history, host (m+1)x(m+1) solve)."""
+    """Pulay CDIIS on stacked [2, N, N] Fock/error matrices: ring-buffer history on the device, only the new Gram row
+    (one fused multiply-reduce; a K = 2 N^2 GEMM with 8x8 output is the shape rocBLAS runs at < 1 TFLOP/s) and the
+    (m+1)x(m+1) solve touch the host."""
 
     def __init__(self, space=8):
-        self.space, self.F, self.E = space, [], []
+        self.space, self.count = space, 0
+        self.F = self.E = None
+        self.B = np.zeros((space, space))
 
     def update(self, f, e):
-        self.F.append(f.clone()); self.E.append(e.clone())
-        if len(self.F) > self.space:
-            self.F.pop(0); self.E.pop(0)
-        m = len(self.F)
-        Es = torch.stack([x.reshape(-1) for x in self.E])
-        B = (Es @ Es.T).cpu().numpy()
+        if self.F is None:
+            self.F = torch.empty((self.space,) + tuple(f.shape), dtype=f.dtype, device=f.device)
+            self.E = torch.empty_like(self.F)
+        slot = self.count % self.space
+        self.F[slot].copy_(f)
+        self.E[slot].copy_(e)
+        self.count += 1
+        m = min(self.count, self.space)
+        dots = (self.E[:m].reshape(m, -1) * e.reshape(1, -1)).sum(dim=1).cpu().numpy()
+        self.B[slot, :m] = dots
+        self.B[:m, slot] = dots
         A = np.zeros((m + 1, m + 1))
         A[0, 1:] = A[1:, 0] = 1.0
-        A[1:, 1:] = B
+        A[1:, 1:] = self.B[:m, :m]
         rhs = np.zeros(m + 1)
         rhs[0] = 1.0
         try:
             c = np.linalg.solve(A, rhs)
         except np.linalg.LinAlgError:
             c = np.linalg.lstsq(A, rhs, rcond=None)[0]
-        out = torch.zeros_like(f)
-        for ci, fi in zip(c[1:], self.F):
-            out += float(ci) * fi
-        return out
+        cw = torch.as_tensor(c[1:], dtype=f.dtype, device=f.device).reshape(m, 1, 1, 1)
+        return (cw * self.F[:m]).sum(dim=0)
 
 
 class UHF(SCF):
     _spin_restricted = False
+    sp2_min_nao = 200   # below this a per-cycle `eigh` of each spin is cheaper than the purification
 
     def __init__(self, mol):
         SCF.__init__(self, mol)
@@ -151,21 +159,49 @@ class UHF(SCF):
             ca, cb = cs[0][:, :na], cs[1][:, :nb]
             return torch.stack([ca @ ca.T, cb @ cb.T])
 
+        # larger matrices: occupied projector of each spin by SP2 purification (same GEMM-only path as RHF, `scf.py`)
+        # instead of a diagonalisation per cycle; orbitals are then only needed once, after convergence
+        use_sp2 = self.eig_method == "sp2" and n >= self.sp2_min_nao
+        sp2_state = [dict(_sp2_iters=self._sp2_iters, _sp2_validated=False) for _ in range(2)]
+
+        def new_density(Fx):
+            if not use_sp2:
+                e_, c_ = orbitals(Fx)
+                return density(c_), (e_, c_)
+            out = []
+            for s_, no in ((0, na), (1, nb)):
+                if no == 0:
+                    out.append(torch.zeros(n, n, dtype=torch.float64, device=eng.device))
+                    continue
+                fo = (Li @ Fx[s_] @ Li.T).contiguous()
+                self._sp2_iters, self._sp2_validated = sp2_state[s_]["_sp2_iters"], sp2_state[s_]["_sp2_validated"]
+                dmo = self._density_sp2(fo, no, orth=True)
+                sp2_state[s_].update(_sp2_iters=self._sp2_iters, _sp2_validated=self._sp2_validated)
+                if dmo is None:      # purification did not converge (vanishing gap): diagonalise this spin
+                    e_, c_ = torch.linalg.eigh(fo)
+                    co = Li.T @ c_[:, :no]
+                    out.append(co @ co.T)
+                else:
+                    out.append(0.5 * (Li.T @ dmo @ Li))
+            return torch.stack(out), None
+
+        def commutator(Fx, dmx):
+            return torch.stack([Fx[s_] @ dmx[s_] @ S - S @ dmx[s_] @ Fx[s_] for s_ in range(2)])
+
         nvo = max(na * (n - na) + nb * (n - nb), 1)
         de = gnorm = 0.0
+        err = commutator(F, dm)
         while cycle < self.max_cycle:
-            err = torch.stack([F[s_] @ dm[s_] @ S - S @ dm[s_] @ F[s_] for s_ in range(2)])
             Fx = diis.update(F, err) if cycle + 1 >= self.diis_start_cycle else F
-            mo_e, mo_c = orbitals(Fx)
-            dm = density(mo_c)
+            dm, mo = new_density(Fx)
+            if mo is not None:
+                mo_e, mo_c = mo
             F, e_el = self._fock_pair(dm)
             e_new = float(e_el) + enuc
-            # orbital gradient of the NEW Fock matrix in the new orbitals: occupied-virtual blocks of both spins
-            g2 = 0.0
-            for s_, no in ((0, na), (1, nb)):
-                fmo = mo_c[s_].T @ F[s_] @ mo_c[s_]
-                g2 = g2 + torch.sum(fmo[no:, :no] ** 2)
-            gnorm = float(torch.sqrt(g2)) / np.sqrt(nvo)
+            err = commutator(F, dm)
+            # |g| = |F_vo| of both spins = |[F', D']|_F / sqrt(2) in the orthonormal basis (D' is a projector)
+            eo = torch.stack([Li @ err[s_] @ Li.T for s_ in range(2)])
+            gnorm = float(torch.sqrt(torch.sum(eo * eo) / 2.0)) / np.sqrt(nvo)
             de = e_new - e_tot
             e_tot = e_new
             cycle += 1
@@ -182,7 +218,7 @@ class UHF(SCF):
             e_new = float(e_el) + enuc
             self._log(4, f"Extra cycle  E= {e_new:.15g}  delta_E= {e_new - e_tot:.3g}")
             e_tot = e_new
-        if mo_e is None:
+        if mo_e is None or (use_sp2 and not (self.converged and self.conv_check)):
             mo_e, mo_c = orbitals(F)
         self._dm, self._fock = dm, F
         self.e_tot = e_tot

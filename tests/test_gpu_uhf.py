@@ -75,3 +75,26 @@ def test_uhf_gradient_matches_finite_differences():
     gu = scf.UHF(h2o).nuc_grad_method().kernel()
     gr = scf.RHF(h2o).nuc_grad_method().kernel()
     assert np.abs(gu - gr).max() < 1e-6
+
+
+def test_uhf_sp2_path_matches_diagonalisation():
+    """N >= 200: the per-spin SP2 purification (no diagonalisation inside the loop) gives the same UHF solution as `eigh`
+    per cycle (benzene radical cation, cc-pVTZ, N = 264)."""
+    import time
+    from pyscf import gto, scf
+    from mi355scf import fixtures
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.charge, mol.spin, mol.verbose = fixtures.BENZENE, "cc-pVTZ", 1, 1, 0
+    mol.build()
+    res = {}
+    for method in ("sp2", "eigh"):
+        mf = scf.UHF(mol).to_gpu()
+        mf.eig_method = method
+        mf.conv_tol = 1e-10
+        t0 = time.time()
+        e = mf.kernel()
+        res[method] = (e, mf.cycles, time.time() - t0, mf.spin_square()[0])
+        assert mf.converged
+    assert abs(res["sp2"][0] - res["eigh"][0]) < 1e-8, res
+    assert abs(res["sp2"][3] - res["eigh"][3]) < 1e-5
+    print("UHF C6H6+ cc-pVTZ:", res)
