@@ -823,13 +823,26 @@ struct XfArgs {
     int check_owner, ni, nj, nk, nl;
 };
 
+// Read-only, wave-uniform operands (work-item records, tile directory, the J-L density rows) go through the
+// constant address space so that they are fetched with scalar loads into SGPRs instead of per-lane vector loads.
+#define MI_CONST_AS __attribute__((address_space(4)))
+template <class T> __device__ inline const MI_CONST_AS T *as_const(const T *p)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const MI_CONST_AS T *)p;
+#pragma clang diagnostic pop
+}
+
 __device__ inline void put_tile(const XfArgs &A, int i, int j, int k, int l, double v)
 {
     int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
     if (I < J || K < L) return;
     int bij = I * (I + 1) / 2 + J, bkl = K * (K + 1) / 2 + L;
     if (bij < bkl) return;
-    int32_t t = A.tile_table[(size_t)bij * (bij + 1) / 2 + bkl];
+    // directory look-ups through the constant address space: known not to alias the tile stores, so the compiler may
+    // overlap the two dependent loads of one element with those of the next instead of serialising load-load-store chains
+    int32_t t = as_const(A.tile_table)[(size_t)bij * (bij + 1) / 2 + bkl];
     if (t < 0) return;
     double w = v;
     if (I == J) w *= 0.5;
@@ -837,7 +850,7 @@ __device__ inline void put_tile(const XfArgs &A, int i, int j, int k, int l, dou
     if (bij == bkl) w *= 0.5;
     int bi = min(BLK, A.nao - I * BLK), bk = min(BLK, A.nao - K * BLK);
     int ii = i & 7, jj = j & 7, kk = k & 7, ll = l & 7;
-    A.tiles[A.tile_off[t] + ((size_t)((jj * 4 + (ll >> 1)) * (bi * bk) + ii * bk + kk) * 2 + (ll & 1))] = w;
+    A.tiles[as_const(A.tile_off)[t] + ((size_t)((jj * 4 + (ll >> 1)) * (bi * bk) + ii * bk + kk) * 2 + (ll & 1))] = w;
 }
 
 // MFMA = true: instantiation with the matrix-core paths for the large angular classes; MFMA = false: lean kernel for
@@ -892,7 +905,7 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
     if (MFMA && GSZ == 64 && mfma_worthwhile(A.nsab, A.nf, A.ne)) {
         for (int m0 = 0; m0 < A.nsab; m0 += 16)
             for (int n0 = 0; n0 < A.nf; n0 += 16) {
-                d4_t x = wave_mfma_tile(Mab, A.ne, 1, A.nsab, E0, A.nf, 1, A.nf, A.ne, m0, n0, lane);
+                d4_t x = wave_mfma_tile(Mab + A.nsab * A.ne /* M^T [e][r] */, 1, A.nsab, A.nsab, E0, A.nf, 1, A.nf, A.ne, m0, n0, lane);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     int r = m0 + (lane >> 4) + 4 * q, f = n0 + (lane & 15);
@@ -911,7 +924,7 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
     if (MFMA && GSZ == 64 && mfma_worthwhile(A.nsab, A.nscd, A.nf)) {
         for (int m0 = 0; m0 < A.nsab; m0 += 16)
             for (int n0 = 0; n0 < A.nscd; n0 += 16) {
-                d4_t o4 = wave_mfma_tile(X, A.nf, 1, A.nsab, Mcd, 1, A.nf, A.nscd, A.nf, m0, n0, lane);
+                d4_t o4 = wave_mfma_tile(X, A.nf, 1, A.nsab, Mcd + A.nscd * A.nf /* M^T [f][c] */, A.nscd, 1, A.nscd, A.nf, m0, n0, lane);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     int r = m0 + (lane >> 4) + 4 * q, c = n0 + (lane & 15);
@@ -1142,7 +1155,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             if (np == 0) continue;
             R.nprim = np;
             R.m_off = (int)Mbuf.size();
-            Mbuf.resize(Mbuf.size() + (size_t)P.nsab * P.ne);
+            Mbuf.resize(Mbuf.size() + (size_t)2 * P.nsab * P.ne); // M [nsab][ne] followed by its transpose [ne][nsab]
             P.recs.push_back(R);
         }
     {   // HRR*c2s matrices of all pairs (OpenMP: this is the costly host part of the setup)
@@ -1153,7 +1166,13 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         for (size_t q = 0; q < all.size(); q++) {
             const ShellH &I = c->shells[all[q]->sh_i], &J = c->shells[all[q]->sh_j];
             double AB[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
-            build_M(I.l, J.l, AB, c2s[I.l], c2s[J.l], Mbuf.data() + all[q]->m_off);
+            double *M = Mbuf.data() + all[q]->m_off;
+            build_M(I.l, J.l, AB, c2s[I.l], c2s[J.l], M);
+            // transposed copy: the MFMA transform reads both operands with the lane index on the contiguous dimension
+            const int nsab = (2 * I.l + 1) * (2 * J.l + 1), ne = ne_of(I.l, J.l);
+            double *Mt = M + (size_t)nsab * ne;
+            for (int r = 0; r < nsab; r++)
+                for (int e = 0; e < ne; e++) Mt[(size_t)e * nsab + r] = M[(size_t)r * ne + e];
         }
     }
     if (Mbuf.size() > (size_t)INT32_MAX) return fail("transformation-matrix buffer exceeds 2^31 doubles");
@@ -1515,17 +1534,6 @@ __device__ inline double reduce8(const double v[8], int lane, int m2, int m1, in
 #pragma unroll
     for (int t = 0; t < 2; t++) b[t] = red_select_xor(a[t], a[t + 2], h1, m1);
     return red_select_xor(b[0], b[1], h0, m0);
-}
-
-// Read-only, wave-uniform operands (work-item records, tile directory, the J-L density rows) go through the
-// constant address space so that they are fetched with scalar loads into SGPRs instead of per-lane vector loads.
-#define MI_CONST_AS __attribute__((address_space(4)))
-template <class T> __device__ inline const MI_CONST_AS T *as_const(const T *p)
-{
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-    return (const MI_CONST_AS T *)p;
-#pragma clang diagnostic pop
 }
 
 template <bool WITH_J, bool WITH_K, bool NT>
