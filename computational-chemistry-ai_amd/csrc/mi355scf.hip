@@ -1094,7 +1094,7 @@ static void setup_eri_dims(EriArgs &E, int la, int lb, int lc, int ld)
     E.la = la; E.lb = lb; E.lc = lc; E.ld = ld;
     E.nmax = la + lb; E.mmax = lc + ld;
     E.nroots = (la + lb + lc + ld) / 2 + 1;
-    E.tsz = (E.nmax + 1) * (E.mmax + 1);
+    E.tsz = ((E.nmax + 1) * (E.mmax + 1)) | 1; // table stride in LDS, odd so that the per-(slot,direction) tables start in different banks
     E.ncomp = ne_of(la, lb) * ne_of(lc, ld);
     int pb = 64 / (3 * E.nroots);
     E.PB = std::max(1, pb);
