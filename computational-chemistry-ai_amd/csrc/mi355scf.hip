@@ -446,11 +446,16 @@ struct Int1eArgs {
     double org[3];
 };
 
+// grid.y = natm + 1: slice y < natm adds the nuclear-attraction contribution of nucleus y (FP64 atomics into a zeroed
+// V: natm-fold more parallelism for the only part that scales with the number of atoms), slice y == natm writes S, T
+// and the dipole blocks.
 __global__ __launch_bounds__(64) void int1e_kernel(Int1eArgs A)
 {
     int pid = blockIdx.x * blockDim.x + threadIdx.x;
     int npair = A.nbas * (A.nbas + 1) / 2;
     if (pid >= npair) return;
+    const int vatom = (int)blockIdx.y < A.natm ? (int)blockIdx.y : -1; // -1: the S/T/dipole slice
+    if (vatom >= 0 && (A.V == nullptr || A.atm[vatom * ATM_SLOTS + 0] == 0)) return;
     int ish = (int)((sqrt(8.0 * pid + 1.0) - 1.0) * 0.5);
     while ((ish + 1) * (ish + 2) / 2 <= pid) ish++;
     while (ish * (ish + 1) / 2 > pid) ish--;
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(64) void int1e_kernel(Int1eArgs A)
                         s[d][i][j + 1] = PB[d] * s[d][i][j] + (i > 0 ? i * h * s[d][i - 1][j] : 0.0) + (j > 0 ? j * h * s[d][i][j - 1] : 0.0);
             }
             double pref = cc * ex * pow(M_PI / p, 1.5);
-            for (int ia = 0; ia < nca; ia++) {
+            for (int ia = 0; ia < (vatom < 0 ? nca : 0); ia++) {
                 int pa[3];
                 cart_pow(la, ia, pa[0], pa[1], pa[2]);
                 for (int ib = 0; ib < ncb; ib++) {
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(64) void int1e_kernel(Int1eArgs A)
             // nuclear attraction by Rys quadrature, nroots = (la+lb)/2 + 1
             int nr = (la + lb) / 2 + 1;
             double pv = cc * ex * 2.0 * M_PI / p;
-            for (int ic = 0; ic < A.natm; ic++) {
+            for (int ic = (vatom < 0 ? A.natm : vatom); ic < (vatom < 0 ? A.natm : vatom + 1); ic++) {
                 double Z = A.atm[ic * ATM_SLOTS + 0];
                 if (Z == 0.0) continue;
                 const double *C = A.env + A.atm[ic * ATM_SLOTS + 1];
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(64) void int1e_kernel(Int1eArgs A)
     double *outs[6] = {A.S, A.T, A.V, A.dip, A.dip ? A.dip + (size_t)A.nao * A.nao : nullptr,
                        A.dip ? A.dip + 2 * (size_t)A.nao * A.nao : nullptr};
     for (int m = 0; m < 6; m++) {
-        if (!outs[m]) continue;
+        if (!outs[m] || (vatom >= 0) != (m == 2)) continue;
         for (int i = 0; i < nsa; i++)
             for (int j = 0; j < nsb; j++) {
                 double v = 0.0;
@@ -556,8 +561,13 @@ __global__ __launch_bounds__(64) void int1e_kernel(Int1eArgs A)
                     for (int b = 0; b < ncb; b++) t += blk[m][a * ncb + b] * cb[b * nsb + j];
                     v += ca[a * nsa + i] * t;
                 }
-                outs[m][(size_t)(ao_i + i) * A.nao + ao_j + j] = v;
-                outs[m][(size_t)(ao_j + j) * A.nao + ao_i + i] = v;
+                if (m == 2) {   // one nucleus' share: accumulate (the diagonal shell pair visits (i,j) and (j,i) itself)
+                    atomicAdd(&outs[m][(size_t)(ao_i + i) * A.nao + ao_j + j], v);
+                    if (ish != jsh) atomicAdd(&outs[m][(size_t)(ao_j + j) * A.nao + ao_i + i], v);
+                } else {
+                    outs[m][(size_t)(ao_i + i) * A.nao + ao_j + j] = v;
+                    outs[m][(size_t)(ao_j + j) * A.nao + ao_i + i] = v;
+                }
             }
     }
 }
@@ -573,7 +583,8 @@ extern "C" int mi_int1e(mi_ctx *c, double *d_S, double *d_T, double *d_V, double
     A.S = d_S; A.T = d_T; A.V = d_V; A.dip = d_dip;
     for (int d = 0; d < 3; d++) A.org[d] = origin ? origin[d] : 0.0;
     int npair = c->nbas * (c->nbas + 1) / 2;
-    hipLaunchKernelGGL(int1e_kernel, dim3((npair + 63) / 64), dim3(64), 0, (hipStream_t)stream, A);
+    if (d_V) HIPCHK(hipMemsetAsync(d_V, 0, sizeof(double) * (size_t)c->nao * c->nao, (hipStream_t)stream));
+    hipLaunchKernelGGL(int1e_kernel, dim3((npair + 63) / 64, c->natm + 1), dim3(64), 0, (hipStream_t)stream, A);
     HIPCHK(hipGetLastError());
     return 0;
 }
