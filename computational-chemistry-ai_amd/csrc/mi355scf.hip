@@ -2611,6 +2611,9 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(Grad1eArgs A)
 {
     int pid = blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= A.nbas * A.nbas) return;
+    // grid.y = natm + 1 slices, as in int1e_kernel: y < natm: nuclear attraction of nucleus y; y == natm: overlap + kinetic
+    const int vatom = (int)blockIdx.y < A.natm ? (int)blockIdx.y : -1;
+    if (vatom >= 0 && A.atm[vatom * ATM_SLOTS + 0] == 0) return;
     int ish = pid / A.nbas, jsh = pid - ish * A.nbas;
     const int32_t *bi = A.bas + ish * BAS_SLOTS, *bj = A.bas + jsh * BAS_SLOTS;
     int la = bi[1], lb = bj[1];
@@ -2653,8 +2656,8 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(Grad1eArgs A)
                         s[d][i][j + 1] = PB[d] * s[d][i][j] + (i > 0 ? i * h * s[d][i - 1][j] : 0.0) + (j > 0 ? j * h * s[d][i][j - 1] : 0.0);
             }
             double pref = cc * ex * pow(M_PI / p, 1.5);
-            // overlap and kinetic: 1-D factors S(i,j), T(i,j) for i in {a-1, a, a+1}
-            for (int ia = 0; ia < nca; ia++) {
+            // overlap and kinetic: 1-D factors S(i,j), T(i,j) for i in {a-1, a, a+1}  (only in the y == natm slice)
+            for (int ia = 0; ia < (vatom < 0 ? nca : 0); ia++) {
                 int pa[3];
                 cart_pow(la, ia, pa[0], pa[1], pa[2]);
                 for (int ib = 0; ib < ncb; ib++) {
@@ -2685,7 +2688,7 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(Grad1eArgs A)
             // nuclear attraction with the differentiated bra: Rys, nroots = (la+lb+1)/2 + 1
             int nr = (la + lb + 1) / 2 + 1;
             double pv = cc * ex * 2.0 * M_PI / p;
-            for (int ic = 0; ic < A.natm; ic++) {
+            for (int ic = (vatom < 0 ? A.natm : vatom); ic < (vatom < 0 ? A.natm : vatom + 1); ic++) {
                 double Z = A.atm[ic * ATM_SLOTS + 0];
                 if (Z == 0.0) continue;
                 const double *C = A.env + A.atm[ic * ATM_SLOTS + 1];
@@ -2742,7 +2745,7 @@ extern "C" int mi_grad_1e(mi_ctx *c, const double *d_D, const double *d_W, doubl
     A.rys = c->rys; A.natm = c->natm; A.nbas = c->nbas; A.nao = c->nao;
     A.D = d_D; A.W = d_W; A.grad = d_grad;
     int n = c->nbas * c->nbas;
-    hipLaunchKernelGGL(int1e_grad_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(int1e_grad_kernel, dim3((n + 63) / 64, c->natm + 1), dim3(64), 0, (hipStream_t)stream, A);
     HIPCHK(hipGetLastError());
     return 0;
 }
