@@ -71,3 +71,37 @@ def test_gpu4pyscf_hessian_surface_rks():
     info = thermo.harmonic_analysis(mol, hess)
     assert info["rotor_type"] == "LINEAR" and len(info["freq_wavenumber"]) == 1
     assert 4300.0 < info["freq_wavenumber"][0] < 4600.0      # B3LYP H2 stretch ~ 4450 cm-1
+
+
+def test_opt_freq_template_dipole_derivative_call_sequence():
+    """The numerical IR fallback of `templates/opt-freq.py:186-262`: `mol.atom_coords(unit='Bohr')`, `mol.copy()`,
+    `mol_plus.set_geom_(coords, unit='Bohr')`, `isinstance(mf, (dft.rks.RKS, dft.uks.UKS))`, `dft.RKS(mol_plus)`,
+    `mf_plus.kernel(dm0=dm0)`, `dip_moment(unit='au')` -- one displacement pair on water B3LYP/6-31G(d); the O-H stretch
+    direction must change the dipole (d mu / d z_H ~ 0.1-0.4 e)."""
+    from pyscf import gto, dft
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.verbose = "O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587", "6-31G(d)", 0
+    mol.build()
+    mf = dft.RKS(mol)
+    mf.xc = "B3LYP"
+    mf.kernel()
+    assert isinstance(mf, (dft.rks.RKS, dft.uks.UKS))
+    mu0 = mf.dip_moment(unit="au")
+    assert mu0.shape == (3,) and 0.7 < np.linalg.norm(mu0) < 0.95          # ~2.1 Debye
+    coords = mol.atom_coords(unit="Bohr")
+    dm0 = mf.make_rdm1()
+    delta = 0.001
+    mus = []
+    for sgn in (+1, -1):
+        c2 = coords.copy()
+        c2[1, 2] += sgn * delta
+        m2 = mol.copy()
+        m2.set_geom_(c2, unit="Bohr")
+        assert np.allclose(m2.atom_coords(), c2) and np.allclose(mol.atom_coords(), coords)
+        f2 = dft.RKS(m2)
+        f2.xc = mf.xc
+        f2.verbose = 0
+        f2.kernel(dm0=dm0)
+        mus.append(f2.dip_moment(unit="au"))
+    dmu = (mus[0] - mus[1]) / (2 * delta)
+    assert np.all(np.isfinite(dmu)) and 0.05 < abs(dmu[2]) < 0.6 and abs(dmu[0]) < 1e-6
