@@ -71,3 +71,17 @@ def test_calculate_bde_template_imports_enumerates_bonds_and_fragments():
     assert scf.UHF.__name__ == "UHF" and dft.UKS.__name__ == "UKS"
     ring = mod.get_all_bonds("c1ccccc1")[0]
     assert sum(1 for b in ring if b[2] == "AROMATIC") == 6
+
+
+def test_opt_freq_template_imports():
+    """`templates/opt-freq.py` imports unchanged: `pyscf.hessian.thermo`, the gpu4pyscf probe,
+    `dft.rks.RKS` / `dft.uks.UKS` for its isinstance checks, and the Hessian factories it calls are all present."""
+    spec = importlib.util.spec_from_file_location("opt_freq", os.path.join(TEMPLATES, "opt-freq.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.GPU4PYSCF_AVAILABLE is True
+    assert callable(mod.numerical_ir_intensities) and callable(mod.thermo.harmonic_analysis) and callable(mod.thermo.thermo)
+    from pyscf import dft, hessian
+    from gpu4pyscf import hessian as gpu_hessian
+    assert hessian.rks.Hessian is gpu_hessian.rks.Hessian
+    assert isinstance(dft.rks.RKS, type) and isinstance(dft.uks.UKS, type)
