@@ -197,3 +197,15 @@ def test_thermo_symmetry_numbers_and_diatomic_model():
     assert abs(res["G_tot"][0] - (res["H_tot"][0] - 298.15 * res["S_tot"][0])) < 1e-15
     # Sackur-Tetrode check: S_trans of a 20.006 amu ideal gas at 298.15 K, 1 atm = 34.9 cal/mol/K (HF: 34.96)
     assert abs(res["S_trans"][0] * 627.509474 * 1000 - 34.94) < 0.1
+
+
+def test_diffuse_pople_sets():
+    """6-31+G / 6-31++G family (`templates/opt-freq.py:86` defaults to '6-31+G**'): shell counts and name folding."""
+    from mi355scf.mole import Mole
+    w = "O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587"
+    assert Mole(atom=w, basis="6-31+G**", verbose=0).build().nao == 28      # O: 4s3p1d = 18, H: 2s1p = 5
+    assert Mole(atom=w, basis="6-31++G(d,p)", verbose=0).build().nao == 30
+    assert Mole(atom=w, basis="6-31+G(d)", verbose=0).build().nao == 22
+    m = Mole(atom=w, basis="6-31+g*", verbose=0).build()
+    exps = sorted({float(m._env[m._bas[i, 5]]) for i in range(m.nbas) if m._bas[i, 2] == 1})
+    assert abs(exps[0] - 0.0845) < 1e-12                                     # the diffuse sp exponent of oxygen
