@@ -14,6 +14,8 @@ ZOO = [("NH3", "N 0 0 0.1; H 0.94 0 -0.27; H -0.47 0.814 -0.27; H -0.47 -0.814 -
        ("H3O+", "O 0 0 0.08; H 0.93 0 -0.2; H -0.465 0.805 -0.2; H -0.465 -0.805 -0.2", "6-31G**", 1),
        ("OH-", "O 0 0 0; H 0 0 0.97", "6-31G*", -1),
        ("H2O2", "O 0 0.7 0; O 0 -0.7 0; H 0.8 0.9 0.5; H -0.8 -0.9 0.5", "def2-TZVP", 0),
+       ("H2O diffuse", "O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587", "6-31++G**", 0),
+       ("ethanol diffuse", "C -0.748 -0.015 0.024; C 0.558 0.420 -0.278; O 1.505 -0.604 0.023; H -1.489 0.772 -0.198; H -0.994 -0.906 -0.566; H -0.789 -0.268 1.091; H 0.622 0.669 -1.345; H 0.822 1.326 0.282; H 1.455 -0.850 0.961", "6-31+G*", 0),
        ("far H2O dimer", "O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587; O 0 0 8.0; H 0 -0.757 8.587; H 0 0.757 8.587", "6-31G", 0)]
 
 
