@@ -590,6 +590,13 @@ class SCF:
             self._log(3, "Dipole moment(X, Y, Z, A.U.): %8.5f, %8.5f, %8.5f" % tuple(out))
         return out
 
+    def density_fit(self, auxbasis=None, **kw):
+        """PySCF idiom `mf.density_fit()` (never called by the reference).  This engine keeps
+        the exact four-centre ERIs resident instead of fitting them, so the call is accepted and changes nothing; results
+        are the un-fitted ones (a density-fitted PySCF run differs from them by its fitting error, 1e-5..1e-4 Ha)."""
+        self._log(3, "density_fit(): not applied -- exact four-centre integrals are used (resident ERI tiles)")
+        return self
+
     def nuc_grad_method(self):
         from . import grad
         return grad.Gradients(self)
