@@ -1794,6 +1794,50 @@ __global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
   }
 }
 
+// Dense (nao^4) copy of the resident tiles for post-SCF methods on small molecules (MP2 behind `pyscf.mp`): every stored
+// element is un-weighted (tiles hold 1/2 per block coincidence) and written to its eight symmetry images.
+__global__ __launch_bounds__(256) void eri_unpack_kernel(const double *tiles, const int64_t *tile_off, const TileInfo *info, int nao,
+                                                         double *out)
+{
+    const TileInfo T = info[blockIdx.x];
+    const int bi = min(BLK, nao - T.I * BLK), bk = min(BLK, nao - T.K * BLK);
+    const int bij = T.I * (T.I + 1) / 2 + T.J, bkl = T.K * (T.K + 1) / 2 + T.L;
+    const double mult = (T.I == T.J ? 2.0 : 1.0) * (T.K == T.L ? 2.0 : 1.0) * (bij == bkl ? 2.0 : 1.0);
+    const double *src = tiles + tile_off[blockIdx.x];
+    const int ntot = BLK * 4 * bi * bk * 2;
+    const size_t n1 = nao, n2 = n1 * nao, n3 = n2 * nao;
+    for (int idx = threadIdx.x; idx < ntot; idx += blockDim.x) {
+        const int lo = idx & 1, t = idx >> 1, pos = t % (bi * bk), jl = t / (bi * bk);
+        const int ii = pos / bk, kk = pos - ii * bk, jj = jl >> 2, ll = (jl & 3) * 2 + lo;
+        const size_t i = T.I * BLK + ii, j = T.J * BLK + jj, k = T.K * BLK + kk, l = T.L * BLK + ll;
+        if (j >= n1 || l >= n1) continue;
+        const double v = mult * src[idx];
+        out[i * n3 + j * n2 + k * n1 + l] = v; out[j * n3 + i * n2 + k * n1 + l] = v;
+        out[i * n3 + j * n2 + l * n1 + k] = v; out[j * n3 + i * n2 + l * n1 + k] = v;
+        out[k * n3 + l * n2 + i * n1 + j] = v; out[l * n3 + k * n2 + i * n1 + j] = v;
+        out[k * n3 + l * n2 + j * n1 + i] = v; out[l * n3 + k * n2 + j * n1 + i] = v;
+    }
+}
+
+extern "C" int mi_eri_unpack(mi_ctx *c, double *d_out, void *stream)
+{
+    if (!c || !d_out) return fail("mi_eri_unpack: null argument");
+    if (!c->eri_ready) return fail("mi_eri_unpack: call mi_eri_prepare first");
+    if (c->nranks != 1) return fail("mi_eri_unpack: needs the whole (unsharded) tile store");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = c->nao;
+    HIPCHK(hipMemsetAsync(d_out, 0, sizeof(double) * n * n * n * n, st));   // screened-out tiles stay zero
+    if (c->n_tiles == 0) return 0;
+    TileInfo *d_info = nullptr;
+    if (upload(&d_info, c->tiles)) return -1;
+    hipLaunchKernelGGL(eri_unpack_kernel, dim3((unsigned)c->n_tiles), dim3(256), 0, st, c->d_tiles, c->d_tile_off, d_info, c->nao, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(d_info);
+    return 0;
+}
+
 __global__ void pad_density_kernel(const double *D, double *Dp, int nao, int ld)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -56,6 +56,7 @@ def lib():
         L.mi_eri_prepare.argtypes = [vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp]
         L.mi_eri_get_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
         L.mi_build_jk.argtypes = [vp, vp, ctypes.c_int, vp, vp, vp]
+        L.mi_eri_unpack.argtypes = [vp, vp, vp]
         L.mi_time_jk_kernel.argtypes = [vp, vp, ctypes.c_int, dp, vp]
         L.mi_time_jk_variant.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, vp]
         L.mi_diis_errvec.argtypes = [vp, vp, vp, vp]
@@ -197,6 +198,16 @@ class Engine:
             J = J[0] if with_j else None
             K = K[0] if with_k else None
         return J, K
+
+    def eri_dense(self):
+        """(ij|kl) as a dense [nao]*4 device tensor (small molecules only: 8 nao^4 bytes)."""
+        if not self.eri_ready:
+            self.prepare_eri()
+        n = self.nao
+        out = self._new(n, n, n, n)
+        with torch.cuda.device(self.device):
+            _check(lib().mi_eri_unpack(self._h, out.data_ptr(), self._stream()))
+        return out
 
     def time_jk_kernel(self, dm, reps=20, with_j=True, with_k=True):
         dm = torch.as_tensor(dm, dtype=torch.float64, device=self.device).contiguous()

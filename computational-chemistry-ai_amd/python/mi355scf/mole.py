@@ -30,7 +30,17 @@ ATOM_OF, ANG_OF, NPRIM_OF, NCTR_OF, KAPPA_OF, PTR_EXP, PTR_COEFF, _RES_BAS = ran
 PTR_ENV_START = 20
 
 
+def split_ghost(symbol):
+    """PySCF ghost-atom spellings ('Ghost:O', 'GHOST-O', 'ghost_O', 'X-O', 'X:O', also with a trailing label such as
+    'Ghost:O1'; `templates/calculate_interaction.py:136,142` writes 'Ghost:' + symbol) -> (is_ghost, element symbol)."""
+    m = re.match(r"^(ghost|x)[\s:_\-]+(.+)$", symbol.strip(), flags=re.IGNORECASE)
+    if m:
+        return True, m.group(2)
+    return False, symbol
+
+
 def charge_of(symbol):
+    symbol = split_ghost(symbol)[1]
     s = re.sub(r"[^A-Za-z]", "", symbol).upper()
     if s not in _Z:
         raise ValueError(f"unknown element symbol '{symbol}'")
@@ -116,7 +126,7 @@ class Mole:
 
     def _basis_for(self, sym):
         b = self.basis
-        pure = re.sub(r"[^A-Za-z]", "", sym)
+        pure = re.sub(r"[^A-Za-z]", "", split_ghost(sym)[1])
         pure = pure[0].upper() + pure[1:].lower()
         if isinstance(b, dict):
             b = b.get(sym, b.get(pure, b.get("default")))
@@ -142,7 +152,7 @@ class Mole:
         atm = np.zeros((natm, 6), dtype=np.int32)
         bas = []
         for ia, (sym, xyz) in enumerate(self._atom):
-            atm[ia, CHARGE_OF] = 0 if sym.upper().startswith(("GHOST", "X-")) else charge_of(sym)
+            atm[ia, CHARGE_OF] = 0 if split_ghost(sym)[0] else charge_of(sym)
             atm[ia, PTR_COORD] = len(env)
             atm[ia, NUC_MOD_OF] = 1
             env.extend(xyz)
@@ -221,7 +231,7 @@ class Mole:
                 12: 23.985041697, 13: 26.98153853, 14: 27.97692653465, 15: 30.97376199842, 16: 31.9720711744,
                 17: 34.968852682, 18: 39.9623831237}
         tab = avg if isotope_avg else main
-        return np.array([tab[int(z)] for z in self.atom_charges()])
+        return np.array([tab[int(z)] if z else 0.0 for z in self.atom_charges()])
 
     def atom_charges(self):
         return self._atm[:, CHARGE_OF].astype(np.int64).copy()
@@ -230,8 +240,10 @@ class Mole:
         return self._atom[i][0]
 
     def atom_pure_symbol(self, i):
-        s = re.sub(r"[^A-Za-z]", "", self._atom[i][0])
-        return s[0].upper() + s[1:].lower()
+        ghost, el = split_ghost(self._atom[i][0])
+        s = re.sub(r"[^A-Za-z]", "", el)
+        s = s[0].upper() + s[1:].lower()
+        return ("Ghost-" + s) if ghost else s
 
     def atom_charge(self, i):
         return int(self._atm[i, CHARGE_OF])

@@ -88,6 +88,10 @@ int mi_build_jk(mi_ctx *ctx, const double *d_D, int n_dm, double *d_J, double *d
 
 /* Time `reps` back-to-back launches of the J/K digestion kernel alone with HIP events on `stream`
  * and return the average milliseconds per launch (bench.py's roofline leg). */
+/* Dense [nao^4] copy of the resident ERIs (chemists' notation (ij|kl), all eight symmetry images) for post-SCF methods on
+ * small molecules: `mp.MP2(mf).kernel()` in templates/calculate_interaction.py:116-120.  Unsharded contexts only. */
+int mi_eri_unpack(mi_ctx *ctx, double *d_out, void *stream);
+
 int mi_time_jk_kernel(mi_ctx *ctx, const double *d_D, int reps, double *ms_per_launch, void *stream);
 /* Same measurement for the J-only (with_k = 0: the pure-functional RKS build) or K-only kernel variant. */
 int mi_time_jk_variant(mi_ctx *ctx, const double *d_D, int with_j, int with_k, int reps, double *ms_per_launch,

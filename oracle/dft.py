@@ -19,9 +19,9 @@ import numpy as np
 from . import oracle as orc
 
 BOHR = 0.52917721092
-_BRAGG = {1: 0.35, 2: 1.40, 3: 1.45, 4: 1.05, 5: 0.85, 6: 0.70, 7: 0.65, 8: 0.60, 9: 0.50, 10: 1.50,
+_BRAGG = {0: 0.35, 1: 0.35, 2: 1.40, 3: 1.45, 4: 1.05, 5: 0.85, 6: 0.70, 7: 0.65, 8: 0.60, 9: 0.50, 10: 1.50,
           11: 1.80, 12: 1.50, 13: 1.25, 14: 1.10, 15: 1.00, 16: 1.00, 17: 1.00, 18: 1.80}
-_TA_XI = {1: 0.8, 2: 0.9, 3: 1.8, 4: 1.4, 5: 1.3, 6: 1.1, 7: 0.9, 8: 0.9, 9: 0.9, 10: 0.9,
+_TA_XI = {0: 1.0, 1: 0.8, 2: 0.9, 3: 1.8, 4: 1.4, 5: 1.3, 6: 1.1, 7: 0.9, 8: 0.9, 9: 0.9, 10: 0.9,
           11: 1.4, 12: 1.3, 13: 1.3, 14: 1.2, 15: 1.1, 16: 1.0, 17: 1.0, 18: 1.0}
 _RAD = [(10, 15, 20), (30, 40, 50), (40, 60, 65), (50, 75, 80), (60, 90, 95), (70, 105, 110)]
 _ANG = [(50, 86, 110), (110, 194, 194), (194, 302, 302), (302, 302, 434), (434, 590, 590), (590, 770, 770)]
@@ -73,7 +73,7 @@ def build_grids(mol, level=3):
     zs = mol.atom_charges()
     R = mol.atom_coords()
     natm = mol.natm
-    rad = np.sqrt(np.array([_BRAGG[int(z)] / BOHR for z in zs]))
+    rad = np.sqrt(np.array([_BRAGG[int(z)] / BOHR for z in zs]))   # index 0: ghost centre (first-period grid, radius 0.35 A)
     rr = rad[:, None] / rad[None, :]
     a = 0.25 * (rr.T - rr)
     a = np.clip(a, -0.5, 0.5)

@@ -252,3 +252,15 @@ def uhf(mol, conv_tol=1e-10, max_cycle=100, dm0=None, verbose=False):
     dm, es, cs = dens(F)
     F, e = fock(dm)
     return e, dm, es, cs
+
+
+def mp2(mol, r=None):
+    """Closed-shell MP2 correlation energy from the oracle's dense ERIs (checker for `mi355scf.mp2.MP2`; small N only)."""
+    r = r or rhf(mol, conv_tol=1e-11)
+    o = Oracle(mol)
+    eri = o.eri_full()
+    c, e, occ = r["mo_coeff"], r["mo_energy"], r["mo_occ"]
+    co, cv, eo, ev = c[:, occ > 0], c[:, occ == 0], e[occ > 0], e[occ == 0]
+    ovov = np.einsum("pqrs,pi,qa,rj,sb->iajb", eri, co, cv, co, cv, optimize=True)
+    d = eo[:, None, None, None] - ev[None, :, None, None] + eo[None, None, :, None] - ev[None, None, None, :]
+    return float(np.sum(ovov / d * (2 * ovov - ovov.transpose(0, 3, 2, 1))))

@@ -85,3 +85,17 @@ def test_opt_freq_template_imports():
     from gpu4pyscf import hessian as gpu_hessian
     assert hessian.rks.Hessian is gpu_hessian.rks.Hessian
     assert isinstance(dft.rks.RKS, type) and isinstance(dft.uks.UKS, type)
+
+
+def test_interaction_and_reaction_templates_import():
+    """`templates/calculate_interaction.py` (needs `pyscf.mp`, 'Ghost:' atoms, 6-31+G*) and
+    `templates/calculate_reaction_energy.py` import unchanged; the counterpoise molecules they build parse."""
+    inter = _load("calculate_interaction")
+    _load("calculate_reaction_energy")
+    atoms1, coords1 = inter.smiles_to_xyz("O")
+    ghost = ["Ghost:" + a for a in atoms1]
+    coords = np.vstack([coords1, coords1 + np.array([0.0, 0.0, 3.0])])
+    mol = inter.create_pyscf_mol(list(atoms1) + ghost, coords, "6-31+G*")
+    assert mol.nelectron == 10 and mol.natm == 6 and list(mol.atom_charges()) == [8, 1, 1, 0, 0, 0]
+    from pyscf import mp
+    assert callable(mp.MP2)
