@@ -42,10 +42,11 @@ class Hessian:
         R = mol.atom_coords()
         n = mol.natm
         H = np.zeros((n, 3, n, 3))
+        dmu = np.zeros((n, 3, 3))          # d mu_c / d R_ix (a.u.), by-product of the same displaced SCFs (IR intensities)
         h = self.step
         for ia in range(n):
             for x in range(3):
-                g = []
+                g, mu = [], []
                 for sgn in (+1.0, -1.0):
                     Rd = R.copy()
                     Rd[ia, x] += sgn * h
@@ -54,12 +55,15 @@ class Hessian:
                     if not c.converged:
                         raise RuntimeError("SCF did not converge at a displaced geometry of the Hessian")
                     g.append(c.nuc_grad_method().kernel())
+                    mu.append(np.asarray(c.dip_moment(unit="au")))
                     c._eng = None
                 H[ia, x] = (g[0] - g[1]) / (2.0 * h)
+                dmu[ia, x] = (mu[0] - mu[1]) / (2.0 * h)
             mf._log(4, f"Hessian: atom {ia + 1}/{n} done")
         Hm = H.reshape(3 * n, 3 * n)
         Hm = 0.5 * (Hm + Hm.T)
         self.de = Hm.reshape(n, 3, n, 3).transpose(0, 2, 1, 3).copy()
+        self.dipole_deriv = dmu
         return self.de
 
     hess = kernel

@@ -105,3 +105,27 @@ def test_opt_freq_template_dipole_derivative_call_sequence():
         mus.append(f2.dip_moment(unit="au"))
     dmu = (mus[0] - mus[1]) / (2 * delta)
     assert np.all(np.isfinite(dmu)) and 0.05 < abs(dmu[2]) < 0.6 and abs(dmu[0]) < 1e-6
+
+
+def test_infrared_module_water_intensities():
+    """`infrared.RHF(mf).kernel()`, `.summary()`, `.freq_info`, `.ir_intensity` (calculate_ir_spectrum.py:90-105).  Water
+    RHF/6-31G(d): literature harmonic IR intensities 107 / 18 / 58 km/mol for the bend / symmetric / antisymmetric stretch
+    [MEM, CCCBDB HF/6-31G*], +-15 %."""
+    from pyscf import gto, scf
+    from pyscf.prop import infrared
+    from pyscf.geomopt.geometric_solver import optimize
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.verbose = "O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587", "6-31G(d)", 0
+    mol.build()
+    mol_eq = optimize(scf.RHF(mol).to_gpu(), maxsteps=50)
+    mf = scf.RHF(mol_eq)
+    mf.conv_tol = 1e-11
+    mf.kernel()
+    ir = infrared.RHF(mf)
+    ir.kernel()
+    ir.summary()
+    freq = ir.freq_info["freq_wavenumber"]
+    inten = ir.ir_intensity
+    assert len(freq) == 3 and inten.shape == (3,)
+    for got, ref in zip(inten, (107.0, 18.0, 58.0)):
+        assert abs(got - ref) < 0.15 * ref + 1.0, (freq, inten)

@@ -99,3 +99,11 @@ def test_interaction_and_reaction_templates_import():
     assert mol.nelectron == 10 and mol.natm == 6 and list(mol.atom_charges()) == [8, 1, 1, 0, 0, 0]
     from pyscf import mp
     assert callable(mp.MP2)
+
+
+def test_ir_spectrum_template_imports():
+    """`templates/calculate_ir_spectrum.py` imports unchanged (`pyscf.prop.infrared`, `pyscf.hessian`)."""
+    mod = _load("calculate_ir_spectrum")
+    assert callable(mod.calculate_ir_spectrum)
+    from pyscf.prop import infrared
+    assert callable(infrared.RHF) and callable(infrared.RKS)
