@@ -197,11 +197,16 @@ class UHF(SCF):
             if mo is not None:
                 mo_e, mo_c = mo
             F, e_el = self._fock_pair(dm)
-            e_new = float(e_el) + enuc
             err = commutator(F, dm)
             # |g| = |F_vo| of both spins = |[F', D']|_F / sqrt(2) in the orthonormal basis (D' is a projector)
             eo = torch.stack([Li @ err[s_] @ Li.T for s_ in range(2)])
-            gnorm = float(torch.sqrt(torch.sum(eo * eo) / 2.0)) / np.sqrt(nvo)
+            ctrl = torch.stack([e_el.reshape(()), torch.sum(eo * eo)])
+            if self._nranks > 1:   # identical control flow on every rank (replicated FP64 work may differ in the last bits)
+                from . import parallel
+                parallel.broadcast0(ctrl, self._pg)
+            ctrl = ctrl.cpu().numpy()
+            e_new = float(ctrl[0]) + enuc
+            gnorm = float(np.sqrt(max(ctrl[1], 0.0) / 2.0)) / np.sqrt(nvo)
             de = e_new - e_tot
             e_tot = e_new
             cycle += 1

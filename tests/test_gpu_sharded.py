@@ -24,10 +24,12 @@ def _worker(rank, world, port, method, q):
     mol.atom = MOLECULES["h2co"]
     mol.basis = "6-31G(d)"
     mol.verbose = 0
+    if method.startswith("U"):          # open shell: the formaldehyde radical cation
+        mol.charge, mol.spin = 1, 1
     mol.build()
-    mf = scf.RHF(mol) if method == "HF" else dft.RKS(mol)
-    if method != "HF":
-        mf.xc = method
+    mf = {"HF": scf.RHF, "UHF": scf.UHF, "UB3LYP": dft.UKS}.get(method, dft.RKS)(mol)
+    if method not in ("HF", "UHF"):
+        mf.xc = method.lstrip("U")
     mf.shard(rank, world)
     e = mf.kernel()
     st = mf.engine.stats()
@@ -37,17 +39,19 @@ def _worker(rank, world, port, method, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("method", ["HF", "B3LYP"])
+@pytest.mark.parametrize("method", ["HF", "B3LYP", "UHF", "UB3LYP"])
 def test_two_rank_sharded_scf_matches_single(method):
     from pyscf import gto, scf, dft
     mol = gto.Mole()
     mol.atom = MOLECULES["h2co"]
     mol.basis = "6-31G(d)"
     mol.verbose = 0
+    if method.startswith("U"):
+        mol.charge, mol.spin = 1, 1
     mol.build()
-    mf = scf.RHF(mol) if method == "HF" else dft.RKS(mol)
-    if method != "HF":
-        mf.xc = method
+    mf = {"HF": scf.RHF, "UHF": scf.UHF, "UB3LYP": dft.UKS}.get(method, dft.RKS)(mol)
+    if method not in ("HF", "UHF"):
+        mf.xc = method.lstrip("U")
     e1 = mf.kernel()
     st1 = mf.engine.stats()
     g1 = mf.nuc_grad_method().kernel()
