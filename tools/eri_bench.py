@@ -20,6 +20,9 @@ def _atoms(key):
 atom = {"benzene": lambda: fixtures.BENZENE, "ibuprofen": lambda: _atoms("CC(C)Cc1ccc(cc1)C(C)C(=O)O"), "c60": lambda: _atoms("C60")}[name]()
 mol = Mole(atom=atom, basis=basis, verbose=0).build()
 eng = Engine(mol)
+for kv in os.environ.get("ERI_OPTS", "").split(","):   # e.g. ERI_OPTS=eri_qloop=8
+    if "=" in kv:
+        eng.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 for rep in range(2):   # second pass reuses the parked tile store: no allocation
     sh = [a for a in sys.argv if a.startswith("--shard=")]
     r_, n_ = (int(x) for x in sh[0].split("=")[1].split("/")) if sh else (0, 1)
