@@ -1971,8 +1971,15 @@ __global__ __launch_bounds__(256) void diis_dots_kernel(const double *hist, cons
 {
     __shared__ double sh[4];
     const double *h = hist + (size_t)blockIdx.x * nn;
-    double s = 0.0;
-    for (size_t i = threadIdx.x; i < nn; i += 256) s = fma(h[i], e[i], s);
+    // eight independent partial sums per thread: the loads of a 13k-element dot are all in flight at once
+    double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = threadIdx.x;
+    for (; i + 7 * 256 < nn; i += 8 * 256) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) p[u] = fma(h[i + u * 256], e[i + u * 256], p[u]);
+    }
+    for (; i < nn; i += 256) p[0] = fma(h[i], e[i], p[0]);
+    double s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
