@@ -3399,6 +3399,35 @@ extern "C" int mi_sp2_iterate(mi_ctx *c, double *d_X, double *d_X2, int nit, dou
     return 0;
 }
 
+// Same passes on two caller-owned [X | X2] buffers (2 n^2 doubles each, X0 in d_A[0 : n^2]) WITHOUT the final copy:
+// *d_res tells which of the two buffers holds {X_nit, X_nit^2}.
+extern "C" int mi_sp2_iterate_pingpong(mi_ctx *c, double *d_A, double *d_B, int nit, double n_occ, double *d_tr, double **d_tr_out,
+                                       double **d_res, void *stream)
+{
+    if (!c || !d_A || !d_B || !d_tr || !d_tr_out || !d_res || nit < 0) return fail("mi_sp2_iterate_pingpong: bad argument");
+    const int n = c->nao;
+    if (n > 512) return fail("mi_sp2_iterate_pingpong: fused path is for N <= 512");
+    hipStream_t st = (hipStream_t)stream;
+    const int kpad = ((n + 15) / 16) * 16;
+    const size_t shm = sizeof(double) * (2 * 16 * (kpad + 4) + 4 * 256);
+    const int nb = (n + 15) / 16;
+    dim3 grid(nb, nb), block(256);
+    const size_t nn = (size_t)n * n;
+    HIPCHK(hipMemsetAsync(d_tr, 0, sizeof(double) * 2 * (nit + 2), st));
+    double *cur = d_A, *nxt = d_B;
+    hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur, cur + nn, d_tr, 1, n, kpad, n_occ, nxt, nxt + nn, d_tr);
+    std::swap(cur, nxt);
+    for (int it = 0; it < nit; it++) {
+        hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur, cur + nn, d_tr + 2 * it, 0, n, kpad, n_occ, nxt, nxt + nn,
+                           d_tr + 2 * (it + 1));
+        std::swap(cur, nxt);
+    }
+    HIPCHK(hipGetLastError());
+    *d_tr_out = d_tr + 2 * nit;
+    *d_res = cur;
+    return 0;
+}
+
 // =================================================================================================
 // Fused elementwise pieces of the SCF cycle (fewer launches per cycle)
 // =================================================================================================

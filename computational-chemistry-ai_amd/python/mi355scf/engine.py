@@ -74,6 +74,7 @@ def lib():
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_sp2_iterate.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, ctypes.POINTER(vp), vp]
+        L.mi_sp2_iterate_pingpong.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
         L.mi_grad_1e.argtypes = [vp, vp, vp, vp, vp]
         L.mi_grad_eri.argtypes = [vp, vp, ctypes.c_double, vp, vp]
         L.mi_grad_eri_spin.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
@@ -297,6 +298,13 @@ class Engine:
         _check(lib().mi_sp2_iterate(self._h, X.data_ptr(), X2.data_ptr(), int(nit), float(nocc), 0, work.data_ptr(),
                                     tr.data_ptr(), ctypes.byref(out), self._stream()))
         return (out.value - tr.data_ptr()) // 8
+
+    def sp2_iterate_pingpong(self, A, B, nit, nocc, tr):
+        """Fused SP2 passes on two [X|X2] buffers, no final copy: returns (result buffer, offset of {tr X, tr X^2} in `tr`)."""
+        out, res = ctypes.c_void_p(), ctypes.c_void_p()
+        _check(lib().mi_sp2_iterate_pingpong(self._h, A.data_ptr(), B.data_ptr(), int(nit), float(nocc), tr.data_ptr(),
+                                             ctypes.byref(out), ctypes.byref(res), self._stream()))
+        return (A if res.value == A.data_ptr() else B), (out.value - tr.data_ptr()) // 8
 
     def fock_energy(self, h, J, K, Vxc, D, kscale, F, scal):
         _check(lib().mi_fock_energy(self._h, h.data_ptr(), J.data_ptr(), K.data_ptr() if K is not None else None,

@@ -61,6 +61,21 @@ class DeviceDIIS:
         self._pending = (slot, m)
         return m
 
+    def next_slot(self):
+        """History slot the next push will use: the SCF step lets its GEMMs write F' and e straight into it."""
+        return self.count % self.space
+
+    def push_inplace(self):
+        """`push` for data already written into `F[next_slot()]` / `E[next_slot()]` (no device copies)."""
+        slot = self.count % self.space
+        self.count += 1
+        m = min(self.count, self.space)
+        if not hasattr(self, "dots_dev"):
+            self.dots_dev = torch.zeros(self.space, dtype=torch.float64, device=self.F.device)
+        self.eng.diis_dots_dev(self.E, self.E[slot], m, self.dots_dev)
+        self._pending = (slot, m)
+        return m
+
     def extrapolate(self, dots):
         slot, m = self._pending
         dots = np.asarray(dots, dtype=np.float64)[:m]
@@ -366,10 +381,15 @@ class SCF:
             mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
             ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2 * n))
         nit = min(self._sp2_iters, 76)
-        eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
         if n <= self.sp2_fused_max and self.sp2_fused:
-            off = eng.sp2_iterate(ws["X"], ws["X2"], nit, float(nocc), ws["work"], ws["tr"])
-            return 2.0 * ws["X"], ws["tr"][off:off + 2]
+            pp = ws.get("pp")
+            if pp is None:   # two [X | X2] buffers: the passes ping-pong between them and the result is read where it lands
+                pp = ws["pp"] = (torch.empty(2, n, n, dtype=torch.float64, device=fo.device),
+                                 torch.empty(2, n, n, dtype=torch.float64, device=fo.device))
+            eng.sp2_init(fo.contiguous(), pp[0][0], ws["b"])
+            res, off = eng.sp2_iterate_pingpong(pp[0], pp[1], nit, float(nocc), ws["tr"])
+            return 2.0 * res[0], ws["tr"][off:off + 2]
+        eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
         # larger N: rocBLAS DGEMM + fused update kernel per step, still without a host sync
         buf = getattr(self, "_sp2_buf", None)
         if buf is None or buf[0].numel() != 2 + n * n:
@@ -450,13 +470,21 @@ class SCF:
         dm = dm.contiguous()
         scal = torch.zeros(2, dtype=torch.float64, device=dm.device)   # [E_elec, |[F',D']|^2]
         fock = self._fock_energy(dm, scal[0:1])
-        fo = Li @ fock @ Li.T
+        # PySCF feeds CDIIS only from cycle `diis_start_cycle` on [MEM]: the initial-guess Fock is not stored.  When it is
+        # stored, the two GEMM chains write F' and the error vector straight into the history slot (no device copies).
+        diis = st["diis"]
+        keep = next_cycle >= self.diis_start_cycle
+        slot = diis.next_slot()
+        fo = torch.matmul(Li @ fock, Li.T, out=diis.F[slot]) if keep else Li @ fock @ Li.T
         m = fo @ st["dmo"]
         eo = torch.empty_like(m)
         self.engine.commutator_norm(m, eo, scal[1:2])  # eo = [F', D'] and its squared norm
-        e_ao = L @ eo @ L.T                            # = F D S - S D F  (PySCF's CDIIS error vector [MEM])
-        # PySCF feeds CDIIS only from cycle `diis_start_cycle` on [MEM]: the initial-guess Fock is not stored
-        nd = st["diis"].push(fo, e_ao) if next_cycle >= self.diis_start_cycle else 0
+        # e_ao = F D S - S D F = L [F', D'] L^T  (PySCF's CDIIS error vector [MEM])
+        if keep:
+            torch.matmul(L @ eo, L.T, out=diis.E[slot])
+            nd = diis.push_inplace()
+        else:
+            nd = 0
         n = fo.shape[0]
         nvo = max((n - st["nocc"]) * st["nocc"], 1)
         parts = ([st["diis"].dots_dev[:nd]] if nd else []) + [scal] + ([sp2_tr] if sp2_tr is not None else [])

@@ -127,6 +127,9 @@ int mi_sp2_update(mi_ctx *ctx, double *d_X, const double *d_X2, double n_occ, do
  * Runs one squaring pass plus `nit` update+square passes; *d_tr_out points at {tr X, tr X^2} (device). */
 int mi_sp2_iterate(mi_ctx *ctx, double *d_X, double *d_X2, int nit, double n_occ, int have_x2,
                    double *d_work, double *d_tr, double **d_tr_out, void *stream);
+/* Same passes on two caller-owned [X | X2] buffers without the final copy; *d_res = the buffer holding the result. */
+int mi_sp2_iterate_pingpong(mi_ctx *ctx, double *d_A, double *d_B, int nit, double n_occ, double *d_tr, double **d_tr_out,
+                            double **d_res, void *stream);
 
 /* Fused elementwise pieces of one SCF cycle (rows a11/a12: get_fock + energy_elec, orbital-gradient norm):
  * mi_fock_energy: F = h + J - kscale*K (+Vxc); *d_scal += sum D*(h + (J - kscale*K)/2).  d_K, d_Vxc may be NULL.
