@@ -20,10 +20,14 @@ class PairDIIS:
     (one fused multiply-reduce; a K = 2 N^2 GEMM with 8x8 output is the shape rocBLAS runs at < 1 TFLOP/s) and the
     (m+1)x(m+1) solve touch the host."""
 
-    def __init__(self, space=8):
+    def __init__(self, space=8, sync=None):
         self.space, self.count = space, 0
         self.F = self.E = None
         self.B = np.zeros((space, space))
+        # sharded runs: rank 0's Gram row is used on every rank.  Replicated FP64 work (eigh, reductions) differs in the last
+        # bits between ranks; extrapolation coefficients computed per rank would feed that difference back and amplify it
+        # (measured: x8 per cycle) until the ranks' densities disagree at 1e-7.
+        self.sync = sync
 
     def update(self, f, e):
         if self.F is None:
@@ -34,7 +38,10 @@ class PairDIIS:
         self.E[slot].copy_(e)
         self.count += 1
         m = min(self.count, self.space)
-        dots = (self.E[:m].reshape(m, -1) * e.reshape(1, -1)).sum(dim=1).cpu().numpy()
+        dots = (self.E[:m].reshape(m, -1) * e.reshape(1, -1)).sum(dim=1)
+        if self.sync is not None:
+            self.sync(dots)
+        dots = dots.cpu().numpy()
         self.B[slot, :m] = dots
         self.B[:m, slot] = dots
         A = np.zeros((m + 1, m + 1))
@@ -139,7 +146,11 @@ class UHF(SCF):
         enuc = mol.energy_nuc()
         conv_tol = self.conv_tol
         conv_tol_grad = self.conv_tol_grad if self.conv_tol_grad is not None else np.sqrt(conv_tol)
-        diis = PairDIIS(self.diis_space)
+        sync = None
+        if self._nranks > 1:
+            from . import parallel
+            sync = lambda t: parallel.broadcast0(t, self._pg)
+        diis = PairDIIS(self.diis_space, sync)
         F, e_el = self._fock_pair(dm)
         e_tot = float(e_el) + enuc
         self._log(4, f"init E= {e_tot:.15g}")
@@ -220,6 +231,9 @@ class UHF(SCF):
             mo_e, mo_c = orbitals(F)
             dm = density(mo_c)
             F, e_el = self._fock_pair(dm)
+            e_el = e_el.reshape(1)
+            if sync is not None:
+                sync(e_el)
             e_new = float(e_el) + enuc
             self._log(4, f"Extra cycle  E= {e_new:.15g}  delta_E= {e_new - e_tot:.3g}")
             e_tot = e_new
