@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def cpu_baseline(mol, label, iters=2):
+def cpu_baseline(mol, label, iters=5):
     """CPU oracle (kind "port"): `iters` direct-SCF cycles (Schwarz-screened 8-fold J/K + numpy DIIS/eig)."""
     import numpy as np
     from oracle import oracle as orc
