@@ -139,7 +139,7 @@ class SCF:
     sp2_fused = True   # small N: one fused HIP launch per SP2 step instead of rocBLAS DGEMM + update kernel
     _sp2_iters = 24
     _sp2_validated = False   # True once an iteration count has passed the checked path for this Fock spectrum
-    sp2_fused_max = 160  # measured: fused wins at N=114 (0.92 -> 0.80 ms/cycle), rocBLAS wins at N=264
+    sp2_fused_max = 272  # measured (ping-pong kernel, no copies): fused wins at N=114 and N=264 (1.73 -> 1.60 ms/cycle), rocBLAS at N=300
     _spin_restricted = True
 
     def __init__(self, mol):
