@@ -107,3 +107,16 @@ def test_ir_spectrum_template_imports():
     assert callable(mod.calculate_ir_spectrum)
     from pyscf.prop import infrared
     assert callable(infrared.RHF) and callable(infrared.RKS)
+
+
+def test_reaction_energy_template_surface():
+    """`templates/calculate_reaction_energy.py`: `gto.M(...)`, `scf.rhf.RHF`, `scf.rohf.ROHF`, `scf.uhf.UHF`, `dft.rks.RKS` in its
+    isinstance dispatch (`:167-174`), `hessian.{RHF,UHF,RKS,UKS}`, `thermo`."""
+    mod = _load("calculate_reaction_energy")
+    from pyscf import gto, scf, dft, hessian
+    h = gto.M(atom="H 0 0 0", basis="sto-3g", charge=0, spin=1)      # calculate_reaction_energy.py:86
+    assert h.nelectron == 1 and h.spin == 1
+    assert scf.rhf.RHF is scf.RHF and isinstance(scf.rohf.ROHF, type) and scf.uhf.UHF is scf.UHF
+    assert all(callable(x) for x in (hessian.RHF, hessian.UHF, hessian.RKS, hessian.UKS))
+    assert isinstance(dft.rks.RKS, type)
+    assert callable(mod.thermo.harmonic_analysis)
