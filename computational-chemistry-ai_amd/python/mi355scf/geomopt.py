@@ -212,6 +212,9 @@ def optimize(mf, maxsteps=100, callback=None, coordsys="internal", **kw):
     optimised geometry.  `coordsys="internal"` (default; redundant primitive internals, Cartesian fallback) or
     "cart"."""
     gs = mf.nuc_grad_method().as_scanner()
+    # forces inside the optimisation loop: derivative quartets screened at 1e-11 instead of 1e-13 (forces change by ~2e-7
+    # Ha/Bohr, three orders below the convergence thresholds; ibuprofen/def2-TZVP gradient 2.2 -> 1.9 s)
+    gs.grad_dtol = kw.pop("grad_dtol", 1e-11)
     mol = mf.mol
     log = lambda msg: mf._log(3, msg)
     log("Step    Energy (Ha)        dE         RMS grad    max grad    RMS disp(A)  max disp(A)")

@@ -278,5 +278,7 @@ class _GradScanner:
         e = mf.kernel(dm0=dm0)
         self.converged = mf.converged
         self.g.mol = self.mol = mol
+        if getattr(self, "grad_dtol", None) is not None:
+            mf.engine.set_option("grad_dtol", self.grad_dtol)   # density-weighted screening of the derivative quartets
         de = self.g.kernel()
         return e, de
