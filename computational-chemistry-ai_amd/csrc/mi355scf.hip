@@ -2092,75 +2092,107 @@ struct AoArgs {
 
 // One thread per grid point, loop over shells (wave-uniform shell data -> scalar loads); stores are
 // coalesced along the grid index.
+// One shell at one grid point with compile-time angular momentum and derivative order: every loop bound is a constant, so
+// the spherical accumulators (up to 10 x 7 doubles for an f shell with second derivatives) live in registers instead of
+// the 528 B of scratch per thread the runtime-l version needed.
+template <int L, int DERIV>
+__device__ __forceinline__ void eval_ao_shell(const AoArgs &A, const int32_t *b, int ish, int64_t g, double x, double y, double z)
+{
+    constexpr int ns = 2 * L + 1;
+    const int np = b[2];
+    const double r2 = x * x + y * y + z * z;
+    double rad = 0.0, drad = 0.0, d2rad = 0.0;
+    for (int p = 0; p < np; p++) {
+        double a = A.env[b[5] + p];
+        double e = A.env[b[6] + p] * exp(-a * r2);
+        rad += e;
+        if (DERIV >= 1) drad -= 2.0 * a * e;
+        if (DERIV >= 2) d2rad += 4.0 * a * a * e;
+    }
+    const double *c2s = A.c2s + A.c2s_off[L];
+    double s[ns], s1[3][ns], s2[6][ns];
+#pragma unroll
+    for (int m = 0; m < ns; m++) {
+        s[m] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) s1[q][m] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) s2[q][m] = 0.0;
+    }
+    double px[L + 1], py[L + 1], pz[L + 1];
+    px[0] = py[0] = pz[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k <= L; k++) { px[k] = px[k - 1] * x; py[k] = py[k - 1] * y; pz[k] = pz[k - 1] * z; }
+    int k = 0;
+#pragma unroll
+    for (int lx = L; lx >= 0; lx--)
+#pragma unroll
+        for (int ly = L - lx; ly >= 0; ly--, k++) {
+            const int lz = L - lx - ly;
+            const double v = px[lx] * py[ly] * pz[lz];
+            double dx = 0.0, dy = 0.0, dz = 0.0, h2[6] = {0, 0, 0, 0, 0, 0};
+            if (DERIV >= 1) {
+                dx = lx ? lx * px[lx > 0 ? lx - 1 : 0] * py[ly] * pz[lz] : 0.0;
+                dy = ly ? ly * px[lx] * py[ly > 0 ? ly - 1 : 0] * pz[lz] : 0.0;
+                dz = lz ? lz * px[lx] * py[ly] * pz[lz > 0 ? lz - 1 : 0] : 0.0;
+            }
+            if (DERIV >= 2) {
+                h2[0] = lx > 1 ? lx * (lx - 1) * px[lx > 1 ? lx - 2 : 0] * py[ly] * pz[lz] : 0.0;
+                h2[1] = (lx && ly) ? lx * ly * px[lx > 0 ? lx - 1 : 0] * py[ly > 0 ? ly - 1 : 0] * pz[lz] : 0.0;
+                h2[2] = (lx && lz) ? lx * lz * px[lx > 0 ? lx - 1 : 0] * py[ly] * pz[lz > 0 ? lz - 1 : 0] : 0.0;
+                h2[3] = ly > 1 ? ly * (ly - 1) * px[lx] * py[ly > 1 ? ly - 2 : 0] * pz[lz] : 0.0;
+                h2[4] = (ly && lz) ? ly * lz * px[lx] * py[ly > 0 ? ly - 1 : 0] * pz[lz > 0 ? lz - 1 : 0] : 0.0;
+                h2[5] = lz > 1 ? lz * (lz - 1) * px[lx] * py[ly] * pz[lz > 1 ? lz - 2 : 0] : 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < ns; m++) {
+                const double cc = c2s[k * ns + m];
+                s[m] += cc * v;
+                if (DERIV >= 1) { s1[0][m] += cc * dx; s1[1][m] += cc * dy; s1[2][m] += cc * dz; }
+                if (DERIV >= 2) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) s2[q][m] += cc * h2[q];
+                }
+            }
+        }
+    const int ao0 = A.shell_ao[ish];
+    const size_t comp = (size_t)A.nao * A.ng;
+    const double xyz[3] = {x, y, z};
+#pragma unroll
+    for (int m = 0; m < ns; m++) {
+        const size_t o = (size_t)(ao0 + m) * A.ng + g;
+        A.ao[o] = rad * s[m];
+        if (DERIV >= 1) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) A.ao[(1 + q) * comp + o] = drad * xyz[q] * s[m] + rad * s1[q][m];
+        }
+        if (DERIV >= 2) {
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = i; j < 3; j++, q++)
+                    A.ao[(4 + q) * comp + o] = d2rad * xyz[i] * xyz[j] * s[m] + (i == j ? drad * s[m] : 0.0) +
+                                               drad * (xyz[i] * s1[j][m] + xyz[j] * s1[i][m]) + rad * s2[q][m];
+        }
+    }
+}
+
+template <int DERIV>
 __global__ __launch_bounds__(256) void eval_ao_kernel(AoArgs A)
 {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= A.ng) return;
     const double gx = A.coords[3 * g], gy = A.coords[3 * g + 1], gz = A.coords[3 * g + 2];
-    const size_t comp = (size_t)A.nao * A.ng;
     for (int ish = 0; ish < A.nbas; ish++) {
         const int32_t *b = A.bas + ish * BAS_SLOTS;
-        const int l = b[1], np = b[2];
         const double *R = A.env + A.atm[b[0] * ATM_SLOTS + 1];
         const double x = gx - R[0], y = gy - R[1], z = gz - R[2];
-        const double r2 = x * x + y * y + z * z;
-        double rad = 0.0, drad = 0.0, d2rad = 0.0;
-        for (int p = 0; p < np; p++) {
-            double a = A.env[b[5] + p];
-            double e = A.env[b[6] + p] * exp(-a * r2);
-            rad += e;
-            drad -= 2.0 * a * e;
-            d2rad += 4.0 * a * a * e;
-        }
-        const double *c2s = A.c2s + A.c2s_off[l];
-        const int ns = 2 * l + 1;
-        double s[2 * LMAX + 1], s1[3][2 * LMAX + 1], s2[6][2 * LMAX + 1];
-        for (int m = 0; m < ns; m++) {
-            s[m] = 0.0;
-            for (int q = 0; q < 3; q++) s1[q][m] = 0.0;
-            for (int q = 0; q < 6; q++) s2[q][m] = 0.0;
-        }
-        double px[LMAX + 1], py[LMAX + 1], pz[LMAX + 1];
-        px[0] = py[0] = pz[0] = 1.0;
-        for (int k = 1; k <= l; k++) { px[k] = px[k - 1] * x; py[k] = py[k - 1] * y; pz[k] = pz[k - 1] * z; }
-        int k = 0;
-        for (int lx = l; lx >= 0; lx--)
-            for (int ly = l - lx; ly >= 0; ly--, k++) {
-                int lz = l - lx - ly;
-                double v = px[lx] * py[ly] * pz[lz];
-                double dx = lx ? lx * px[lx - 1] * py[ly] * pz[lz] : 0.0;
-                double dy = ly ? ly * px[lx] * py[ly - 1] * pz[lz] : 0.0;
-                double dz = lz ? lz * px[lx] * py[ly] * pz[lz - 1] : 0.0;
-                double h2[6] = {0, 0, 0, 0, 0, 0};
-                if (A.deriv >= 2) {
-                    h2[0] = lx > 1 ? lx * (lx - 1) * px[lx - 2] * py[ly] * pz[lz] : 0.0;
-                    h2[1] = (lx && ly) ? lx * ly * px[lx - 1] * py[ly - 1] * pz[lz] : 0.0;
-                    h2[2] = (lx && lz) ? lx * lz * px[lx - 1] * py[ly] * pz[lz - 1] : 0.0;
-                    h2[3] = ly > 1 ? ly * (ly - 1) * px[lx] * py[ly - 2] * pz[lz] : 0.0;
-                    h2[4] = (ly && lz) ? ly * lz * px[lx] * py[ly - 1] * pz[lz - 1] : 0.0;
-                    h2[5] = lz > 1 ? lz * (lz - 1) * px[lx] * py[ly] * pz[lz - 2] : 0.0;
-                }
-                for (int m = 0; m < ns; m++) {
-                    double cc = c2s[k * ns + m];
-                    s[m] += cc * v; s1[0][m] += cc * dx; s1[1][m] += cc * dy; s1[2][m] += cc * dz;
-                    if (A.deriv >= 2)
-                        for (int q = 0; q < 6; q++) s2[q][m] += cc * h2[q];
-                }
-            }
-        const int ao0 = A.shell_ao[ish];
-        const double xyz[3] = {x, y, z};
-        for (int m = 0; m < ns; m++) {
-            size_t o = (size_t)(ao0 + m) * A.ng + g;
-            A.ao[o] = rad * s[m];
-            if (A.deriv >= 1)
-                for (int q = 0; q < 3; q++) A.ao[(1 + q) * comp + o] = drad * xyz[q] * s[m] + rad * s1[q][m];
-            if (A.deriv >= 2) {
-                int q = 0;
-                for (int i = 0; i < 3; i++)
-                    for (int j = i; j < 3; j++, q++)
-                        A.ao[(4 + q) * comp + o] = d2rad * xyz[i] * xyz[j] * s[m] + (i == j ? drad * s[m] : 0.0) +
-                                                   drad * (xyz[i] * s1[j][m] + xyz[j] * s1[i][m]) + rad * s2[q][m];
-            }
+        switch (b[1]) {   // wave-uniform
+        case 0: eval_ao_shell<0, DERIV>(A, b, ish, g, x, y, z); break;
+        case 1: eval_ao_shell<1, DERIV>(A, b, ish, g, x, y, z); break;
+        case 2: eval_ao_shell<2, DERIV>(A, b, ish, g, x, y, z); break;
+        default: eval_ao_shell<3, DERIV>(A, b, ish, g, x, y, z); break;
         }
     }
 }
@@ -2173,7 +2205,10 @@ extern "C" int mi_eval_ao(mi_ctx *c, const double *d_coords, int64_t ng, int der
     A.atm = c->d_atm; A.bas = c->d_bas; A.env = c->d_env; A.shell_ao = c->d_shell_ao; A.c2s = c->d_c2s;
     for (int i = 0; i <= LMAX + 1; i++) A.c2s_off[i] = c->c2s_off[i];
     A.nbas = c->nbas; A.nao = c->nao; A.deriv = deriv; A.coords = d_coords; A.ng = ng; A.ao = d_ao;
-    hipLaunchKernelGGL(eval_ao_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    const dim3 grid((unsigned)((ng + 255) / 256)), block(256);
+    if (deriv <= 0) hipLaunchKernelGGL(eval_ao_kernel<0>, grid, block, 0, (hipStream_t)stream, A);
+    else if (deriv == 1) hipLaunchKernelGGL(eval_ao_kernel<1>, grid, block, 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(eval_ao_kernel<2>, grid, block, 0, (hipStream_t)stream, A);
     HIPCHK(hipGetLastError());
     return 0;
 }
