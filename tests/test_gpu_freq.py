@@ -129,3 +129,35 @@ def test_infrared_module_water_intensities():
     assert len(freq) == 3 and inten.shape == (3,)
     for got, ref in zip(inten, (107.0, 18.0, 58.0)):
         assert abs(got - ref) < 0.15 * ref + 1.0, (freq, inten)
+
+
+def test_benzene_b3lyp_frequencies_ir_and_thermo_against_literature():
+    """Benzene B3LYP/6-31G(d), optimised with `optimize()`: harmonic frequencies (literature 414 / 622 ... 3212 cm-1), the
+    dominant IR band (out-of-plane C-H bend, 694 cm-1, ~75 km/mol), ZPE 63.3 kcal/mol, sigma = 12, S(298 K) = 64.3 cal/mol/K
+    [MEM].  Exercises the whole chain: RKS, analytic gradient, internal-coordinate optimiser, semi-numerical Hessian,
+    dipole derivatives, harmonic analysis, RRHO."""
+    from pyscf import gto, dft
+    from pyscf.hessian import thermo
+    from pyscf.prop import infrared
+    from pyscf.geomopt.geometric_solver import optimize
+    from mi355scf import fixtures
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.verbose = fixtures.BENZENE, "6-31G*", 0
+    mol.build()
+    mf = dft.RKS(mol)
+    mf.xc = "B3LYP"
+    mol_eq = optimize(mf, maxsteps=50)
+    mf = dft.RKS(mol_eq)
+    mf.xc, mf.conv_tol = "B3LYP", 1e-11
+    mf.kernel()
+    ir = infrared.RKS(mf)
+    info = ir.kernel()
+    f = info["freq_wavenumber"]
+    assert len(f) == 30 and (f > 0).all()
+    assert abs(f[0] - 414.0) < 6.0 and abs(f[2] - 622.0) < 6.0 and abs(f[-1] - 3212.0) < 12.0
+    k = int(np.argmax(ir.ir_intensity))
+    assert abs(f[k] - 694.0) < 8.0 and 60.0 < ir.ir_intensity[k] < 95.0
+    t = thermo.thermo(mf, info["freq_au"], 298.15, 101325)
+    assert abs(t["ZPE"][0] * 627.509 - 63.3) < 0.5
+    assert t["sym_number"][0] == 12
+    assert abs(t["S_tot"][0] * 627509 - 64.3) < 1.0
