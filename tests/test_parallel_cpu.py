@@ -39,6 +39,23 @@ def _worker(rank, world, port, q):
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     parallel.all_reduce_sum(t)
     ok = ok and float(t) == world * (world + 1) / 2
+    # control scalars and the CDIIS Gram row: rank 0's copy becomes authoritative on every rank (parallel.broadcast0), and the
+    # host-side extrapolation of mi355scf.uhf.PairDIIS with that hook gives identical coefficients on all ranks even when the
+    # ranks' error vectors differ in the last bits
+    c = torch.tensor([1.0 + 1e-15 * rank, 2.0 - rank], dtype=torch.float64)
+    parallel.broadcast0(c)
+    ok = ok and c.tolist() == [1.0, 2.0]
+    from mi355scf.uhf import PairDIIS
+    d = PairDIIS(4, sync=lambda x: parallel.broadcast0(x))
+    g = torch.Generator().manual_seed(5)
+    outs = []
+    for it in range(3):
+        f = torch.randn(2, 4, 4, generator=g, dtype=torch.float64)
+        e = torch.randn(2, 4, 4, generator=g, dtype=torch.float64) * (1.0 + 1e-13 * rank)   # last-bit rank differences
+        outs.append(d.update(f, e))
+    ref = outs[-1].clone()
+    parallel.broadcast0(ref)
+    ok = ok and float((outs[-1] - ref).abs().max()) == 0.0
     q.put((rank, bool(ok)))
     import torch.distributed as dist
     dist.destroy_process_group()
