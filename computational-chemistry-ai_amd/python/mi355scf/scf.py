@@ -141,6 +141,7 @@ class SCF:
     _sp2_validated = False   # True once an iteration count has passed the checked path for this Fock spectrum
     sp2_fused_max = 272  # measured (ping-pong kernel, no copies): fused wins at N=114 and N=264 (1.73 -> 1.60 ms/cycle), rocBLAS at N=300
     _spin_restricted = True
+    level_shift = 0.0    # Hartree; virtual-orbital shift applied to the Fock matrix that is diagonalised / purified
 
     def __init__(self, mol):
         if not isinstance(mol, Mole):
@@ -512,6 +513,10 @@ class SCF:
             fo = st["diis"].extrapolate(st["dots"])
         else:
             fo = st["fo"]
+        if self.level_shift and use_diis:
+            # PySCF `level_shift`: raise the virtual space of the matrix the new orbitals come from, F' + s (1 - D'/2), D' the
+            # current projector x 2; it leaves a converged solution unchanged and is not applied to the final (extra) cycle
+            fo = fo + self.level_shift * (torch.eye(fo.shape[0], dtype=fo.dtype, device=fo.device) - 0.5 * st["dmo"])
         tr_dev = None
         use_sp2 = self.eig_method == "sp2" and not want_mo
         if use_sp2 and self._sp2_validated and 0 < nocc < fo.shape[0] and not st.get("_redo"):

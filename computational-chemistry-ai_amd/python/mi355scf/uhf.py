@@ -204,6 +204,8 @@ class UHF(SCF):
         err = commutator(F, dm)
         while cycle < self.max_cycle:
             Fx = diis.update(F, err) if cycle + 1 >= self.diis_start_cycle else F
+            if self.level_shift:   # F_s + shift (S - S D_s S): virtual space of each spin raised (AO form of PySCF's level_shift)
+                Fx = Fx + self.level_shift * (S.unsqueeze(0) - torch.stack([S @ dm[s_] @ S for s_ in range(2)]))
             dm, mo = new_density(Fx)
             if mo is not None:
                 mo_e, mo_c = mo

@@ -66,3 +66,23 @@ def test_charged_closed_shell_species_match_oracle(atom, charge):
     ref = orc.rhf(mol)
     assert mf.converged and ref["converged"] and abs(e - ref["e_tot"]) < 1e-8
     assert mf.mo_occ.sum() == mol.nelectron
+
+
+def test_level_shift_leaves_the_converged_solution_unchanged():
+    """`mf.level_shift` (PySCF attribute): same converged energy with and without the virtual-space shift, for the
+    restricted (SP2 purification of the shifted matrix) and the unrestricted driver."""
+    from pyscf import gto, scf
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.verbose = "O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587", "6-31G*", 0
+    mol.build()
+    e0 = scf.RHF(mol).kernel()
+    mf = scf.RHF(mol)
+    mf.level_shift = 0.3
+    assert abs(mf.kernel() - e0) < 1e-8 and mf.converged
+    rad = gto.Mole()
+    rad.atom, rad.basis, rad.spin, rad.verbose = "N 0 0 0; H 0 -0.8 0.6; H 0 0.8 0.6", "6-31G*", 1, 0
+    rad.build()
+    eu = scf.UHF(rad).kernel()
+    mu = scf.UHF(rad)
+    mu.level_shift = 0.3
+    assert abs(mu.kernel() - eu) < 1e-8 and mu.converged
