@@ -62,7 +62,7 @@ static int host_threads()
     }();
     return n;
 }
-extern "C" int mi_abi_version(void) { return 1; }
+extern "C" int mi_abi_version(void) { return 2; }
 
 // =================================================================================================
 // Real solid harmonics (generic l): coefficients of the unit-normalised real harmonics r^l Y_lm in
@@ -237,6 +237,7 @@ struct mi_ctx {
     std::vector<int64_t> tile_off;
     std::vector<RunRec> runs;
     int32_t *d_tile_table = nullptr;     // [nbp(nbp+1)/2] -> local tile index or -1
+    uint8_t *d_tile_present = nullptr;   // sharded contexts only: 1 where the slot is resident on another rank
     int64_t *d_tile_off = nullptr;
     int *d_tile_I = nullptr;
     RunRec *d_runs = nullptr;
@@ -250,6 +251,7 @@ struct mi_ctx {
     int ldp = 0;
     double *d_red = nullptr;
     mi_eri_stats stats{};
+    int64_t mem_need_bytes = 0, mem_free_bytes = 0; // of the last mi_eri_prepare (also when it returned MI_ERR_NOMEM)
     bool eri_ready = false;
     // tunables (mi_set_option)
     int opt_runmax = 0;      // tiles per J/K work item (0 = auto: ntiles/2048 clamped to [8,64])
@@ -385,8 +387,10 @@ static void free_eri(mi_ctx *c)
             }
         c->pc[i].recs.clear(); c->pc[i].q.clear();
     }
-    void *ptrs[] = {c->d_prim, c->d_M, c->d_tile_table, c->d_tile_off, c->d_tile_I, c->d_runs, c->d_tiles, c->d_segs, c->d_wave_seg};
+    void *ptrs[] = {c->d_prim, c->d_M, c->d_tile_table, c->d_tile_off, c->d_tile_I, c->d_runs, c->d_tiles, c->d_segs, c->d_wave_seg,
+                    c->d_tile_present};
     for (void *p : ptrs) if (p) hipFree(p);
+    c->d_tile_present = nullptr;
     c->d_prim = c->d_M = nullptr; c->d_tile_table = nullptr; c->d_tile_off = nullptr; c->d_tile_I = nullptr;
     c->d_runs = nullptr; c->d_tiles = nullptr; c->d_segs = nullptr; c->d_wave_seg = nullptr;
     c->eri_ready = false;
@@ -1111,6 +1115,65 @@ static void setup_eri_dims(EriArgs &E, int la, int lb, int lc, int ld)
     E.PB = std::max(1, pb);
 }
 
+// Sharding plan of the resident tile store: enumerate the (J,K,L) runs that survive the block-pair
+// Schwarz test, then deal them to ranks longest-processing-time first (largest run to the least loaded rank) by the bytes a
+// J/K build streams for them.  Pure host code and a pure function of its arguments, so every rank derives the same plan.
+struct RunPlan { int J, K, L, count, owner; int64_t bytes; };
+
+static void plan_runs(int nao, const std::vector<double> &Qblk, double qmax, double tol, int nranks, std::vector<RunPlan> &plan)
+{
+    const int nblk = (nao + BLK - 1) / BLK, nbp = nblk * (nblk + 1) / 2;
+    auto bsize = [&](int B) { return std::min(BLK, nao - B * BLK); };
+    plan.clear();
+    for (int kl = 0, K = 0, L = 0; kl < nbp; kl++) {
+        if (Qblk[kl] * qmax >= tol) {
+            const int bk = bsize(K);
+            for (int J = 0; J < nblk; J++) {
+                RunPlan r{J, K, L, 0, 0, 0};
+                for (int I = J; I < nblk; I++) {
+                    int ij = I * (I + 1) / 2 + J;
+                    if (ij < kl || Qblk[ij] * Qblk[kl] < tol) continue;
+                    r.count++;
+                    r.bytes += (int64_t)BLK * 4 * bsize(I) * bk * 2 * 8;
+                }
+                if (r.count) plan.push_back(r);
+            }
+        }
+        if (++L > K) { K++; L = 0; }
+    }
+    if (nranks <= 1) return;
+    std::vector<int> ord(plan.size());
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return plan[a].bytes > plan[b].bytes; });
+    // least-loaded rank: binary heap of (load, rank); ties go to the lower rank so the plan is reproducible
+    std::vector<std::pair<int64_t, int>> heap(nranks);
+    for (int r = 0; r < nranks; r++) heap[r] = {0, r};
+    auto cmp = [](const std::pair<int64_t, int> &a, const std::pair<int64_t, int> &b) { return a > b; }; // min-heap
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    for (int o : ord) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        plan[o].owner = heap.back().second;
+        heap.back().first += plan[o].bytes;
+        std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+}
+
+// Host-only view of the plan (no GPU, no context): bytes streamed per rank for a given block-pair Schwarz table
+// qblk[nbp] (nbp = nblk(nblk+1)/2, nblk = ceil(nao/8), pair index I(I+1)/2+J).  Used by the CPU tests of the balance.
+extern "C" int mi_plan_shards(int nao, const double *qblk, double tol, int nranks, int64_t *bytes_per_rank, int64_t *runs_per_rank)
+{
+    if (nao <= 0 || !qblk || nranks < 1 || !bytes_per_rank) return fail("mi_plan_shards: bad argument");
+    const int nblk = (nao + BLK - 1) / BLK, nbp = nblk * (nblk + 1) / 2;
+    std::vector<double> Q(qblk, qblk + nbp);
+    double qmax = 0.0;
+    for (double v : Q) qmax = std::max(qmax, v);
+    std::vector<RunPlan> plan;
+    plan_runs(nao, Q, qmax, tol, nranks, plan);
+    for (int r = 0; r < nranks; r++) { bytes_per_rank[r] = 0; if (runs_per_rank) runs_per_rank[r] = 0; }
+    for (const RunPlan &p : plan) { bytes_per_rank[p.owner] += p.bytes; if (runs_per_rank) runs_per_rank[p.owner]++; }
+    return 0;
+}
+
 extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void *stream)
 {
     if (!c) return fail("mi_eri_prepare: null context");
@@ -1273,8 +1336,8 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     }
 
     lap("sort pairs");
-    // ---- 4. tiles and runs.  Run = tiles sharing (J,K,L), ordered by I; long runs are split.
-    const int RUNMAX = 1 << 30; // runs are kept whole here (sharding unit); J/K work items are cut below
+    // ---- 4. tiles and runs.  Run = tiles sharing (J,K,L), ordered by I.  Runs are the sharding unit: plan_runs deals them
+    // to ranks longest-processing-time first by streamed bytes (every rank computes the same plan).
     std::vector<int> bpI(nbp), bpJ(nbp);
     for (int I = 0, n = 0; I < nblk; I++)
         for (int J = 0; J <= I; J++, n++) { bpI[n] = I; bpJ[n] = J; }
@@ -1282,40 +1345,39 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     c->tiles.clear(); c->tile_off.clear(); c->runs.clear();
     std::vector<int32_t> table((size_t)nbp * (nbp + 1) / 2, -1);
     int64_t off = 0, nuniq = 0;
-    int64_t run_counter = 0;
-    for (int kl = 0; kl < nbp; kl++) {
-        int K = bpI[kl], L = bpJ[kl];
-        if (Qblk[kl] * qmax < tol) continue;
-        for (int J = 0; J < nblk; J++) {
-            RunRec cur{J, K, L, 0, 0};
-            bool mine = false;
+    {
+        std::vector<RunPlan> plan;
+        plan_runs(c->nao, Qblk, qmax, tol, nranks, plan);
+        std::vector<uint8_t> present(nranks > 1 ? table.size() : 0, 0); // sharded store: slots that live on SOME rank
+        for (const RunPlan &rp : plan) {
+            const int J = rp.J, K = rp.K, L = rp.L, kl = K * (K + 1) / 2 + L;
+            if (rp.owner != rank) {
+                for (int I = J; I < nblk; I++) {
+                    int ij = I * (I + 1) / 2 + J;
+                    if (ij >= kl && Qblk[ij] * Qblk[kl] >= tol) present[(size_t)ij * (ij + 1) / 2 + kl] = 1;
+                }
+                continue;
+            }
+            RunRec cur{J, K, L, (int)c->tiles.size(), 0};
             for (int I = J; I < nblk; I++) {
                 int ij = I * (I + 1) / 2 + J;
                 if (ij < kl) continue;
                 if (Qblk[ij] * Qblk[kl] < tol) continue;
-                if (cur.count == 0) {
-                    mine = (run_counter % nranks) == rank;
-                    run_counter++;
-                    cur.first = (int)c->tiles.size();
-                }
-                if (mine) {
-                    table[(size_t)ij * (ij + 1) / 2 + kl] = (int32_t)c->tiles.size();
-                    c->tiles.push_back({I, J, K, L});
-                    c->tile_off.push_back(off);
-                    int bi = bsize(I), bj = bsize(J), bk = bsize(K), bl = bsize(L);
-                    off += (int64_t)BLK * 4 * bi * bk * 2; // j is always padded to 8 rows (J==last implies I==last: rare)
-                    int64_t nij = (I > J) ? (int64_t)bi * bj : (int64_t)bi * (bi + 1) / 2;
-                    int64_t nkl = (K > L) ? (int64_t)bk * bl : (int64_t)bk * (bk + 1) / 2;
-                    nuniq += (ij > kl) ? nij * nkl : nij * (nij + 1) / 2;
-                }
+                table[(size_t)ij * (ij + 1) / 2 + kl] = (int32_t)c->tiles.size();
+                c->tiles.push_back({I, J, K, L});
+                c->tile_off.push_back(off);
+                int bi = bsize(I), bj = bsize(J), bk = bsize(K), bl = bsize(L);
+                off += (int64_t)BLK * 4 * bi * bk * 2; // j is always padded to 8 rows (J==last implies I==last: rare)
+                int64_t nij = (I > J) ? (int64_t)bi * bj : (int64_t)bi * (bi + 1) / 2;
+                int64_t nkl = (K > L) ? (int64_t)bk * bl : (int64_t)bk * (bk + 1) / 2;
+                nuniq += (ij > kl) ? nij * nkl : nij * (nij + 1) / 2;
                 cur.count++;
-                if (cur.count == RUNMAX) {
-                    if (mine) c->runs.push_back(cur);
-                    cur.count = 0;
-                }
             }
-            if (cur.count > 0 && mine) c->runs.push_back(cur);
+            if (cur.count != rp.count) return fail("internal: run plan / tile enumeration mismatch");
+            c->runs.push_back(cur);
         }
+        if (c->d_tile_present) { hipFree(c->d_tile_present); c->d_tile_present = nullptr; }
+        if (nranks > 1 && upload(&c->d_tile_present, present)) return -1;
     }
     c->n_tiles = (int64_t)c->tiles.size();
     c->tile_doubles = off;
@@ -1395,10 +1457,13 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     size_t freeb = 0, totb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totb));
     freeb += (size_t)g_arena[c->device & 15].doubles * 8; // a parked store is reusable (or freed) by arena_take
+    c->mem_need_bytes = (int64_t)off * 8;
+    c->mem_free_bytes = (int64_t)freeb;
     if ((size_t)off * 8 + ((size_t)1 << 30) > freeb) {
         hipFree(d_work); hipFree(d_comp);
-        return fail("resident ERI store needs %.1f GB but only %.1f GB of HBM is free; shard over more GPUs",
-                    off * 8e-9, freeb * 1e-9);
+        fail("resident ERI store needs %.1f GB but only %.1f GB of HBM is free; shard over more GPUs",
+             off * 8e-9, freeb * 1e-9);
+        return MI_ERR_NOMEM; // sizes: mi_eri_get_memory
     }
     c->tile_alloc = std::max<int64_t>(off, 1);
     {
@@ -1493,6 +1558,31 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     c->stats.n_quartets = nquart;
     c->stats.seconds_eri = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     c->eri_ready = true;
+    return 0;
+}
+
+// Schwarz factors q[ish][jsh] = sqrt(max |(ab|ab)|) of the shell pairs kept by the last mi_eri_prepare (0 for pairs dropped
+// as negligible: q * q_max < tol), host array [nbas][nbas] (tests: against the oracle's restatement of CVHFnr_int2e_q_cond).
+extern "C" int mi_schwarz_get(const mi_ctx *c, double *q)
+{
+    if (!c || !q) return fail("mi_schwarz_get: null argument");
+    if (!c->eri_ready) return fail("mi_schwarz_get: call mi_eri_prepare first");
+    std::fill(q, q + (size_t)c->nbas * c->nbas, 0.0);
+    for (int ci = 0; ci < NPC; ci++) {
+        const PairClass &P = c->pc[ci];
+        for (size_t r = 0; r < P.recs.size(); r++) {
+            q[(size_t)P.recs[r].sh_i * c->nbas + P.recs[r].sh_j] = P.q[r];
+            q[(size_t)P.recs[r].sh_j * c->nbas + P.recs[r].sh_i] = P.q[r];
+        }
+    }
+    return 0;
+}
+
+extern "C" int mi_eri_get_memory(const mi_ctx *c, int64_t *need_bytes, int64_t *free_bytes)
+{
+    if (!c || !need_bytes || !free_bytes) return fail("mi_eri_get_memory: null argument");
+    *need_bytes = c->mem_need_bytes;
+    *free_bytes = c->mem_free_bytes;
     return 0;
 }
 
@@ -1835,6 +1925,49 @@ extern "C" int mi_eri_unpack(mi_ctx *c, double *d_out, void *stream)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     hipFree(d_info);
+    return 0;
+}
+
+// One shell quartet (ish jsh|ksh lsh) read back from the resident tiles: element -> canonical tile position (the inverse of
+// put_tile), un-weighted.  NaN where the tile is not resident on this rank (sharded store), 0 where it was screened out.
+__global__ void eri_read_quartet_kernel(const double *tiles, const int64_t *tile_off, const int32_t *table, int nao, int ai, int ni,
+                                        int aj, int nj, int ak, int nk, int al, int nl, const uint8_t *present, double *out)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ni * nj * nk * nl) return;
+    int d = idx % nl, c = (idx / nl) % nk, b = (idx / (nl * nk)) % nj, a = idx / (nl * nk * nj);
+    int i = ai + a, j = aj + b, k = ak + c, l = al + d;
+    if ((i >> 3) < (j >> 3)) { int t = i; i = j; j = t; }
+    if ((k >> 3) < (l >> 3)) { int t = k; k = l; l = t; }
+    int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
+    int bij = I * (I + 1) / 2 + J, bkl = K * (K + 1) / 2 + L;
+    if (bij < bkl) { int t = i; i = k; k = t; t = j; j = l; l = t; t = bij; bij = bkl; bkl = t; I = i >> 3; J = j >> 3; K = k >> 3; L = l >> 3; }
+    const size_t slot = (size_t)bij * (bij + 1) / 2 + bkl;
+    const int32_t t = table[slot];
+    if (t < 0) { out[idx] = (present && present[slot]) ? __builtin_nan("") : 0.0; return; }
+    const double mult = (I == J ? 2.0 : 1.0) * (K == L ? 2.0 : 1.0) * (bij == bkl ? 2.0 : 1.0);
+    const int bi = min(BLK, nao - I * BLK), bk = min(BLK, nao - K * BLK);
+    const int ii = i & 7, jj = j & 7, kk = k & 7, ll = l & 7;
+    out[idx] = mult * tiles[tile_off[t] + ((size_t)((jj * 4 + (ll >> 1)) * (bi * bk) + ii * bk + kk) * 2 + (ll & 1))];
+}
+
+extern "C" int mi_eri_read_quartet(mi_ctx *c, int ish, int jsh, int ksh, int lsh, double *out)
+{
+    if (!c || !out) return fail("mi_eri_read_quartet: null argument");
+    if (!c->eri_ready) return fail("mi_eri_read_quartet: call mi_eri_prepare first");
+    const int sh[4] = {ish, jsh, ksh, lsh};
+    for (int s_ : sh) if (s_ < 0 || s_ >= c->nbas) return fail("mi_eri_read_quartet: shell index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    int ao[4], n[4];
+    for (int q = 0; q < 4; q++) { ao[q] = c->shells[sh[q]].ao; n[q] = 2 * c->shells[sh[q]].l + 1; }
+    const int tot = n[0] * n[1] * n[2] * n[3];
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_out, sizeof(double) * tot));
+    hipLaunchKernelGGL(eri_read_quartet_kernel, dim3((tot + 255) / 256), dim3(256), 0, nullptr, c->d_tiles, c->d_tile_off, c->d_tile_table,
+                       c->nao, ao[0], n[0], ao[1], n[1], ao[2], n[2], ao[3], n[3], c->d_tile_present, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, d_out, sizeof(double) * tot, hipMemcpyDeviceToHost));
+    hipFree(d_out);
     return 0;
 }
 
@@ -3145,15 +3278,26 @@ __global__ void grad_reduce_copies_kernel(const double *copies, int natm3, doubl
     grad[idx] += s;
 }
 
-extern "C" int mi_grad_eri_spin(mi_ctx *c, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, void *stream);
+extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, int rank, int nranks,
+                                   void *stream);
 
 extern "C" int mi_grad_eri(mi_ctx *c, const double *d_D, double hyb, double *d_grad, void *stream)
 {
-    return mi_grad_eri_spin(c, d_D, nullptr, hyb, d_grad, stream);
+    return c ? mi_grad_eri_sharded(c, d_D, nullptr, hyb, d_grad, c->rank, c->nranks, stream) : fail("mi_grad_eri: null argument");
 }
 
 extern "C" int mi_grad_eri_spin(mi_ctx *c, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, void *stream)
 {
+    return c ? mi_grad_eri_sharded(c, d_D, d_Dspin, hyb, d_grad, c->rank, c->nranks, stream) : fail("mi_grad_eri: null argument");
+}
+
+// (rank, nranks): which share of the derivative-quartet batches this call evaluates.  It is an ARGUMENT, not the split of
+// the last mi_eri_prepare: in direct mode the tile store is prepared group by group (rank*ng + v of nranks*ng) while the
+// gradient is still shared between the nranks processes only.
+extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, int rank, int nranks,
+                                   void *stream)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("mi_grad_eri: bad rank/nranks");
     if (!c || !d_D || !d_grad) return fail("mi_grad_eri: null argument");
     if (!c->eri_ready) return fail("mi_grad_eri: call mi_eri_prepare first");
     HIPCHK(hipSetDevice(c->device));
@@ -3269,9 +3413,9 @@ extern "C" int mi_grad_eri_spin(mi_ctx *c, const double *d_D, const double *d_Ds
                 auto tc0 = std::chrono::steady_clock::now();
                 if (dbg) hipStreamSynchronize(st);
                 int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / Ep.ncomp), (int64_t)1 << 21);
-                if (c->nranks > 1) per = std::min<int64_t>(per, std::max<int64_t>(1024, ntask / (8 * c->nranks)));
+                if (nranks > 1) per = std::min<int64_t>(per, std::max<int64_t>(1024, ntask / (8 * nranks)));
                 for (int64_t t0 = 0; t0 < ntask; t0 += per) {
-                    if ((int)((batch_counter++) % c->nranks) != c->rank) continue; // batches dealt round-robin to ranks
+                    if ((int)((batch_counter++) % nranks) != rank) continue; // batches dealt round-robin to ranks
                     int nb = (int)std::min<int64_t>(per, ntask - t0);
                     Ep.t0 = t0; Ep.ntask = nb;
                     if (launch_eri(c, Ep, nb, st)) return -1;

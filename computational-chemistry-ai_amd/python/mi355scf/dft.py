@@ -9,7 +9,7 @@ block are rocBLAS DGEMMs (FP64 MFMA) through torch.matmul.
 import numpy as np
 import torch
 
-from .grids import Grids
+from .grids import Grids, _grid_generation
 from .scf import RHF
 
 XC_IDS = {"slater": 1, "b88": 2, "vwn_rpa": 3, "vwn5": 4, "lyp": 5, "pbe_x": 6, "pbe_c": 7}
@@ -56,11 +56,11 @@ class RKS(RHF):
 
     def reset(self, mol=None):
         super().reset(mol)
+        old = self.grids
         self.grids = Grids(self.mol)
+        self.grids.level, self.grids.prune = old.level, old.prune   # user settings survive scanner / optimize() resets
         self._pruned = False
-        lvl = getattr(self, "_grid_level", None)
-        if lvl is not None:
-            self.grids.level = lvl
+        self._ao_cache_key = self._ao_cache = None                  # AO values of the old geometry: drop (and free) them
         return self
 
     def _setup(self):
@@ -106,7 +106,7 @@ class RKS(RHF):
     def _ao_cache_for(self, nao, npts, ncomp):
         """AO values on this rank's grid points are kept resident between SCF cycles when they fit in a quarter
         of the free HBM (benzene/cc-pVTZ 1.2 GB, ibuprofen/def2-TZVP 7.1 GB); invalidated with the grid."""
-        key = (id(self.grids.coords), nao, npts, ncomp)
+        key = (self.grids.generation, nao, npts, ncomp)   # generation: bumped whenever the point set changes
         if getattr(self, "_ao_cache_key", None) != key:
             self._ao_cache_key, self._ao_cache = key, None
             need = 8.0 * ncomp * nao * npts
@@ -142,6 +142,7 @@ class RKS(RHF):
             self._log(4, f"Drop grids {ng - nkeep}")
             self.grids.coords = coords[keep].contiguous()
             self.grids.weights = weights[keep].contiguous()
+            self.grids.generation = next(_grid_generation)
             if self.grids.atom_of is not None:
                 self.grids.atom_of = self.grids.atom_of[keep.cpu().numpy()]
 

@@ -20,6 +20,17 @@ class EngineError(RuntimeError):
     pass
 
 
+class EngineOutOfMemory(EngineError):
+    """`mi_eri_prepare` returned MI_ERR_NOMEM: this rank's share of the tile store exceeds free HBM."""
+
+    def __init__(self, msg, need_bytes, free_bytes):
+        super().__init__(msg)
+        self.need_bytes, self.free_bytes = need_bytes, free_bytes
+
+
+MI_ERR_NOMEM = -2
+
+
 class _Stats(ctypes.Structure):
     _fields_ = [("n_tiles", ctypes.c_int64), ("n_runs", ctypes.c_int64), ("stored_bytes", ctypes.c_int64),
                 ("n_unique_eri", ctypes.c_int64), ("n_quartets", ctypes.c_int64), ("seconds_eri", ctypes.c_double)]
@@ -78,12 +89,28 @@ def lib():
         L.mi_grad_1e.argtypes = [vp, vp, vp, vp, vp]
         L.mi_grad_eri.argtypes = [vp, vp, ctypes.c_double, vp, vp]
         L.mi_grad_eri_spin.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
+        L.mi_grad_eri_sharded.argtypes = [vp, vp, vp, ctypes.c_double, vp, ctypes.c_int, ctypes.c_int, vp]
+        L.mi_eri_get_memory.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        L.mi_eri_read_quartet.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
+        L.mi_schwarz_get.argtypes = [vp, dp]
+        L.mi_plan_shards.argtypes = [ctypes.c_int, dp, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                     ctypes.POINTER(ctypes.c_int64)]
         L.mi_fock_energy.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp]
         L.mi_commutator_norm.argtypes = [vp, vp, vp, vp, vp]
         L.mi_c2s_table.argtypes = [ctypes.c_int, dp]
         L.mi_rys_roots_host.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp]
         _lib = L
     return _lib
+
+
+def plan_shards(nao, qblk, tol, nranks):
+    """Host-only sharding plan (no GPU needed): (bytes per rank, runs per rank) for a block-pair Schwarz table."""
+    q = np.ascontiguousarray(qblk, dtype=np.float64)
+    b = np.zeros(nranks, dtype=np.int64)
+    r = np.zeros(nranks, dtype=np.int64)
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    _check(lib().mi_plan_shards(int(nao), _dp(q), float(tol), int(nranks), b.ctypes.data_as(i64p), r.ctypes.data_as(i64p)))
+    return b, r
 
 
 def release_cache():
@@ -170,9 +197,33 @@ class Engine:
     # --- rows a3, a4 ---------------------------------------------------------------------------
     def prepare_eri(self, tol=1e-13, rank=0, nranks=1):
         with torch.cuda.device(self.device):
-            _check(lib().mi_eri_prepare(self._h, float(tol), int(rank), int(nranks), self._stream()))
+            rc = lib().mi_eri_prepare(self._h, float(tol), int(rank), int(nranks), self._stream())
+        if rc == MI_ERR_NOMEM:
+            self.eri_ready = False
+            need, free = self.eri_memory()
+            raise EngineOutOfMemory(lib().mi_last_error().decode(), need, free)
+        _check(rc)
         self.eri_ready = True
         return self.stats()
+
+    def eri_memory(self):
+        """(bytes the last prepare_eri needed, free HBM bytes it saw)."""
+        need, free = ctypes.c_int64(), ctypes.c_int64()
+        _check(lib().mi_eri_get_memory(self._h, ctypes.byref(need), ctypes.byref(free)))
+        return need.value, free.value
+
+    def schwarz(self):
+        """q[nbas, nbas] = sqrt(max |(ab|ab)|) of the shell pairs kept by prepare_eri (0: dropped)."""
+        q = np.zeros((len(self._bas), len(self._bas)))
+        _check(lib().mi_schwarz_get(self._h, _dp(q)))
+        return q
+
+    def eri_read_quartet(self, i, j, k, l):
+        """(ij|kl) shell block read back from the resident tiles (tests): NumPy [di,dj,dk,dl]."""
+        d = [2 * int(self._bas[s_, 1]) + 1 for s_ in (i, j, k, l)]
+        out = np.zeros(d)
+        _check(lib().mi_eri_read_quartet(self._h, int(i), int(j), int(k), int(l), _dp(out)))
+        return out
 
     def stats(self):
         s = _Stats()
@@ -278,12 +329,13 @@ class Engine:
     def grad_1e(self, D, W, grad):
         _check(lib().mi_grad_1e(self._h, D.data_ptr(), W.data_ptr(), grad.data_ptr(), self._stream()))
 
-    def grad_eri(self, D, hyb, grad, spin_density=None):
-        """D: total density; spin_density: Da - Db for UHF/UKS (None: closed shell)."""
+    def grad_eri(self, D, hyb, grad, spin_density=None, rank=0, nranks=1):
+        """D: total density; spin_density: Da - Db for UHF/UKS (None: closed shell); (rank, nranks): this process's share
+        of the derivative-quartet batches (explicit: in direct mode the last prepare_eri split is a tile group, not a rank)."""
         if not self.eri_ready:
             self.prepare_eri()
-        _check(lib().mi_grad_eri_spin(self._h, D.data_ptr(), spin_density.data_ptr() if spin_density is not None else None,
-                                      float(hyb), grad.data_ptr(), self._stream()))
+        _check(lib().mi_grad_eri_sharded(self._h, D.data_ptr(), spin_density.data_ptr() if spin_density is not None else None,
+                                         float(hyb), grad.data_ptr(), int(rank), int(nranks), self._stream()))
 
     # --- row a11: SP2 purification helpers ------------------------------------------------------
     def sp2_init(self, f_orth, X, work):

@@ -94,7 +94,7 @@ class Gradients:
             hyb = parse_xc(mf.xc)[0]
         t0 = time.time()
         g2 = torch.zeros_like(g)
-        eng.grad_eri(dm.contiguous(), hyb, g2)
+        eng.grad_eri(dm.contiguous(), hyb, g2, rank=mf._rank, nranks=mf._nranks)
         tm["grad_eri"] = time.time() - t0
         if mf._nranks > 1:   # derivative-quartet batches are dealt round-robin to ranks inside mi_grad_eri
             from . import parallel
@@ -148,7 +148,7 @@ class UGradients(Gradients):
             from .dft import parse_xc
             hyb = parse_xc(mf.xc)[0]
         g2 = torch.zeros_like(g)
-        eng.grad_eri(D, hyb, g2, spin_density=M)
+        eng.grad_eri(D, hyb, g2, spin_density=M, rank=mf._rank, nranks=mf._nranks)
         if mf._nranks > 1:
             from . import parallel
             parallel.all_reduce_sum(g2, mf._pg)
@@ -222,11 +222,12 @@ class FDGradients:
         mol = mf.mol.set_geom_(coords, unit="Bohr", inplace=False)
         mol.verbose = 0
         clone = mf.__class__(mol)
-        for k in ("xc", "conv_tol", "max_cycle", "eig_method", "init_guess", "direct_scf_tol"):
+        for k in ("xc", "conv_tol", "max_cycle", "eig_method", "init_guess", "direct_scf_tol", "level_shift", "diis_space",
+                  "diis_start_cycle"):
             if hasattr(mf, k):
                 setattr(clone, k, getattr(mf, k))
         if hasattr(mf, "grids"):
-            clone.grids.level = mf.grids.level
+            clone.grids.level, clone.grids.prune = mf.grids.level, mf.grids.prune
         clone.verbose = 0
         clone.conv_tol = min(mf.conv_tol, 1e-10)
         e = clone.kernel(dm0=dm0)

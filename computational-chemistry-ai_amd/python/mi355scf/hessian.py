@@ -23,11 +23,12 @@ class Hessian:
         mol = mf.mol.set_geom_(coords, unit="Bohr", inplace=False)
         mol.verbose = 0
         clone = mf.__class__(mol)
-        for k in ("xc", "max_cycle", "eig_method", "init_guess", "direct_scf_tol", "small_rho_cutoff"):
+        for k in ("xc", "max_cycle", "eig_method", "init_guess", "direct_scf_tol", "small_rho_cutoff", "level_shift", "diis_space",
+                  "diis_start_cycle"):
             if hasattr(mf, k) and getattr(mf, k) is not None:
                 setattr(clone, k, getattr(mf, k))
         if hasattr(mf, "grids") and hasattr(clone, "grids"):
-            clone.grids.level = mf.grids.level
+            clone.grids.level, clone.grids.prune = mf.grids.level, mf.grids.prune
         clone.verbose = 0
         clone.conv_tol = min(mf.conv_tol, 1e-10)
         clone.conv_tol_grad = 1e-6

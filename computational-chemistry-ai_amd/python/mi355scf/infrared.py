@@ -29,7 +29,7 @@ class Infrared:
         self.dipole_deriv = h.dipole_deriv
         mol = self.base.mol
         info = thermo.harmonic_analysis(mol, self.hessian)
-        mass = mol.atom_mass_list(isotope_avg=False)
+        mass = mol.atom_mass_list(isotope_avg=True)
         n = mol.natm
         # mass-weighted orthonormal modes from the normalised Cartesian ones: L_ik = x_ik sqrt(m_i) / |...|
         modes = info["norm_mode"] * np.sqrt(mass)[None, :, None]

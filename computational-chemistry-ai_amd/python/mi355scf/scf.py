@@ -230,11 +230,8 @@ class SCF:
                 self.timing["eri_seconds"] = st["seconds_eri"]
                 self._log(4, f"resident ERI store: {st['n_tiles']} tiles, {st['stored_bytes'] / 1e6:.1f} MB, "
                              f"{st['n_quartets']} shell quartets in {st['seconds_eri']:.3f} s")
-            except _engine.EngineError as e:
-                if "resident ERI store needs" not in str(e):
-                    raise
-                import re
-                need, free = (float(x) for x in re.findall(r"([0-9.]+) GB", str(e))[:2])
+            except _engine.EngineOutOfMemory as e:   # MI_ERR_NOMEM: sizes come through the ABI (mi_eri_get_memory)
+                need, free = e.need_bytes * 1e-9, e.free_bytes * 1e-9
                 self._stream_groups = int(np.ceil(need / max(0.8 * free, 1.0)))
                 self._log(3, f"ERI tensor shard ({need:.0f} GB) exceeds free HBM ({free:.0f} GB): direct mode, "
                              f"{self._stream_groups} tile groups are re-evaluated and digested every Fock build")

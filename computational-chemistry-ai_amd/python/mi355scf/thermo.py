@@ -50,8 +50,11 @@ def _projector_trans_rot(mass, coords):
 
 def harmonic_analysis(mol, hess, exclude_trans=True, exclude_rot=True, imaginary_freq=True, mass=None):
     if mass is None:
-        mass = mol.atom_mass_list(isotope_avg=False)
+        # isotope-averaged masses, like `thermo()` below and PySCF's `harmonic_analysis` default [MEM; parity unpinned]
+        mass = mol.atom_mass_list(isotope_avg=True)
     mass = np.asarray(mass, dtype=float)
+    if np.any(mass <= 0.0):
+        raise ValueError("harmonic_analysis: massless centres (ghost atoms) cannot be mass-weighted; pass `mass=` explicitly")
     n = mol.natm
     coords = mol.atom_coords()
     H = np.asarray(hess)

@@ -28,10 +28,10 @@ class UKS(UHF):
 
     def reset(self, mol=None):
         UHF.reset(self, mol)
+        old = self.grids
         self.grids = Grids(self.mol)
-        lvl = getattr(self, "_grid_level", None)
-        if lvl is not None:
-            self.grids.level = lvl
+        self.grids.level, self.grids.prune = old.level, old.prune
+        self._ao_cache_key = self._ao_cache = None
         return self
 
     def _setup(self):

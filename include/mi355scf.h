@@ -66,6 +66,26 @@ int mi_int1e(mi_ctx *ctx, double *d_S, double *d_T, double *d_V, double *d_dip, 
  * Replaces: libcint int2e_sph + libcvhf CVHFnr_int2e_q_cond [MEM] / gpu4pyscf libgvhf_rys [MEM],
  * reached from mf.kernel() -> get_jk (templates/calculate_energy.py:155; optimize_geometry.py:90). */
 int mi_eri_prepare(mi_ctx *ctx, double tol, int rank, int nranks, void *stream);
+/* mi_eri_prepare returns MI_ERR_NOMEM (instead of -1) when this rank's share of the tile store does not fit in free HBM;
+ * the caller then shards over more GPUs or falls back to the direct mode.  mi_eri_get_memory reports the bytes the last
+ * mi_eri_prepare needed and the free HBM it saw (valid after success and after MI_ERR_NOMEM). */
+#define MI_ERR_NOMEM (-2)
+int mi_eri_get_memory(const mi_ctx *ctx, int64_t *need_bytes, int64_t *free_bytes);
+
+/* Sharding plan without a GPU or a context: the (J,K,L) tile runs that survive the block-pair Schwarz table
+ * qblk[nblk(nblk+1)/2] (nblk = ceil(nao/8); entry I(I+1)/2+J = max Schwarz factor of the shell pairs touching AO blocks I,J)
+ * are dealt to `nranks` ranks longest-processing-time first by streamed bytes -- the same plan mi_eri_prepare follows
+ * ("deal cost-balanced batches").  Outputs: bytes and runs per rank. */
+int mi_plan_shards(int nao, const double *qblk, double tol, int nranks, int64_t *bytes_per_rank, int64_t *runs_per_rank);
+
+/* Schwarz factors of the last mi_eri_prepare: q[nbas][nbas] (host), q_ab = sqrt(max |(ab|ab)|), 0 for dropped pairs.
+ * Replaces: libcvhf CVHFnr_int2e_q_cond [MEM]. */
+int mi_schwarz_get(const mi_ctx *ctx, double *q);
+
+/* Test/debug: one shell quartet (ish jsh|ksh lsh) read back from the resident tiles into host memory
+ * out[2li+1][2lj+1][2lk+1][2ll+1]; 0 where Schwarz screening dropped the tile, NaN where the tile lives on another rank.
+ * Lets the parity tests compare individual integrals with libcint-style int2e_sph shell blocks [MEM] (oracle: orc_eri_shell). */
+int mi_eri_read_quartet(mi_ctx *ctx, int ish, int jsh, int ksh, int lsh, double *out);
 
 /* Statistics of the resident ERI store. */
 typedef struct {
@@ -86,12 +106,12 @@ int mi_eri_get_stats(const mi_ctx *ctx, mi_eri_stats *out);
  * RYS_build_jk [MEM], reached from get_jk / get_veff inside mf.kernel(). */
 int mi_build_jk(mi_ctx *ctx, const double *d_D, int n_dm, double *d_J, double *d_K, void *stream);
 
-/* Time `reps` back-to-back launches of the J/K digestion kernel alone with HIP events on `stream`
- * and return the average milliseconds per launch (bench.py's roofline leg). */
 /* Dense [nao^4] copy of the resident ERIs (chemists' notation (ij|kl), all eight symmetry images) for post-SCF methods on
  * small molecules: `mp.MP2(mf).kernel()` in templates/calculate_interaction.py:116-120.  Unsharded contexts only. */
 int mi_eri_unpack(mi_ctx *ctx, double *d_out, void *stream);
 
+/* Time `reps` back-to-back launches of the J/K digestion kernel alone with HIP events on `stream`
+ * and return the average milliseconds per launch (bench.py's roofline leg). */
 int mi_time_jk_kernel(mi_ctx *ctx, const double *d_D, int reps, double *ms_per_launch, void *stream);
 /* Same measurement for the J-only (with_k = 0: the pure-functional RKS build) or K-only kernel variant. */
 int mi_time_jk_variant(mi_ctx *ctx, const double *d_D, int with_j, int with_k, int reps, double *ms_per_launch,
@@ -187,6 +207,10 @@ int mi_grad_eri(mi_ctx *ctx, const double *d_D, double hyb, double *d_grad, void
 /* Open-shell form (UHF/UKS, templates/calculate_bde.py:224 optimises radicals): d_D = Da + Db, d_Dspin = Da - Db
  * (NULL: closed shell); the exchange part contracts sum_s Ds x Ds = (D x D + M x M) / 2. */
 int mi_grad_eri_spin(mi_ctx *ctx, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, void *stream);
+/* Same with the share of the derivative-quartet batches given explicitly (the two entry points above use the
+ * (rank, nranks) of the last mi_eri_prepare, which in direct mode is a tile GROUP index, not the process's rank). */
+int mi_grad_eri_sharded(mi_ctx *ctx, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, int rank,
+                        int nranks, void *stream);
 
 /* d_vmat[nao][nao] += ao0 . aow^T over the grid block (split-K FP64 MFMA kernel; rocBLAS has no split-K for
  * this tiny-M,N / huge-K shape and runs it at < 1 TFLOP/s).  The caller symmetrises (Vxc = vmat + vmat^T). */

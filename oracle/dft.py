@@ -313,9 +313,9 @@ def nr_rks(mol, coords, weights, xc, dm, block=20000, rho_cut=1e-10):
     return nelec, exc, vmat + vmat.T, hyb
 
 
-def rks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-9, max_cycle=50, verbose=False, small_rho_cutoff=1e-7):
+def rks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-9, max_cycle=50, verbose=False, small_rho_cutoff=1e-7, oracle=None):
     coords, weights = build_grids(mol, level)
-    o = orc.Oracle(mol)
+    o = oracle if oracle is not None else orc.Oracle(mol)
     info = {}
     grid = {"c": coords, "w": weights, "pruned": small_rho_cutoff <= 1e-20}
 
@@ -342,7 +342,7 @@ def rks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-9, max_cycle=50, verbose
             e2 -= 0.25 * hyb * float(np.sum(dm * K))
         return v, e2
 
-    r = orc.rhf(mol, dm0=dm0, conv_tol=conv_tol, max_cycle=max_cycle, veff_fn=veff, verbose=verbose)
+    r = orc.rhf(mol, dm0=dm0, conv_tol=conv_tol, max_cycle=max_cycle, veff_fn=veff, verbose=verbose, oracle=o)
     r["nelec_grid"] = info.get("nelec")
     r["ngrids"] = info.get("ngrids", len(weights))
     return r

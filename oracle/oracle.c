@@ -21,6 +21,8 @@
  *   orc_eri_shell    -> libcint int2e_sph                                        (row a4)
  *   orc_jk_direct    -> libcvhf CVHFnr_direct_drv + nrs8 J/K digestion           (rows a5, a6)
  *   orc_eri_full     -> mol.intor('int2e')                                       (test helper)
+ *   orc_incore_*     -> mol.intor('int2e', aosym='s8') cached by the SCF object, and
+ *   orc_jk_incore    -> libcvhf CVHFnrs8_incore_drv (PySCF's in-core J/K)        (rows a5, a6)
  *
  * Basis arrays follow the libcint atm/bas/env convention (include/mi355scf.h); nctr must be 1.
  */
@@ -640,6 +642,209 @@ long orc_jk_direct(const int *atm, int natm, const int *bas, int nbas, const dou
     free_pairs(pp, nbas);
     free(q); free(loc);
     return nquart;
+}
+
+/* ---------- public: in-core J/K from packed ERIs ------------------------------------------------- */
+
+/* What PySCF's CPU path does when the 8-fold-unique ERI array fits `max_memory` (N = 264 is 4.9 GB): the SCF object
+ * caches `mol.intor('int2e', aosym='s8')` once and every cycle runs `_vhf.incore(eri, dm)` -> CVHFnrs8_incore_drv [MEM]
+ * (call site in the reference: templates/calculate_energy.py:199-206, the CPU rung `scf.RHF(mol).kernel()`).
+ *
+ * Layout: row ij = i(i+1)/2 + j (AO indices, i >= j) holds (ij|kl) for kl = 0..ij at buf[row_off[ij] + kl].  With
+ * row_off[ij] = ij(ij+1)/2 this is exactly the s8 array.  For bench.py's BOUNDED CPU sample only the rows of every
+ * `stride`-th shell pair (pair index % stride == phase) are kept (row_off = -1 elsewhere).
+ *
+ * orc_incore_layout -> doubles needed, fills row_off[nao(nao+1)/2].
+ * orc_incore_fill   -> evaluates the rows' quartets (Schwarz q_ij q_kl >= tol), returns the number of shell quartets.
+ * orc_jk_incore     -> J, K (this row subset's contribution; the full matrices for stride = 1). */
+long orc_incore_layout(const int *bas, int nbas, int stride, int phase, long *row_off)
+{
+    int nao = orc_nao(bas, nbas);
+    int *loc = (int *)malloc(sizeof(int) * (nbas + 1));
+    ao_offsets(bas, nbas, loc);
+    long npair = (long)nao * (nao + 1) / 2, off = 0;
+    for (long n = 0; n < npair; n++) row_off[n] = -1;
+    for (int si = 0; si < nbas; si++)
+        for (int sj = 0; sj <= si; sj++) {
+            long P = (long)si * (si + 1) / 2 + sj;
+            if (stride > 1 && P % stride != phase) continue;
+            for (int I = loc[si]; I < loc[si + 1]; I++)
+                for (int J = loc[sj]; J < loc[sj + 1] && J <= I; J++) {
+                    long ij = (long)I * (I + 1) / 2 + J;
+                    row_off[ij] = off;
+                    off += ij + 1;
+                }
+        }
+    free(loc);
+    return off;
+}
+
+long orc_incore_fill(const int *atm, int natm, const int *bas, int nbas, const double *env, double tol, int stride,
+                     int phase, const long *row_off, double *buf)
+{
+    int *loc = (int *)malloc(sizeof(int) * (nbas + 1));
+    ao_offsets(bas, nbas, loc);
+    double *q = (double *)malloc(sizeof(double) * nbas * nbas);
+    orc_schwarz(atm, natm, bas, nbas, env, q);
+    pair_t *pp = all_pairs(atm, bas, nbas, env);
+    long nquart = 0;
+    int npair = nbas * (nbas + 1) / 2;
+#pragma omp parallel reduction(+ : nquart)
+    {
+        double *cart = (double *)malloc(sizeof(double) * QBUF * 3);
+#pragma omp for schedule(dynamic, 1)
+        for (int P = npair - 1; P >= 0; P--) {
+            if (stride > 1 && P % stride != phase) continue;
+            int si = (int)((sqrt(8.0 * P + 1) - 1) / 2);
+            while ((si + 1) * (si + 2) / 2 <= P) si++;
+            while (si * (si + 1) / 2 > P) si--;
+            int sj = P - si * (si + 1) / 2;
+            /* every ket shell pair (sk >= sl) with sk <= si can hold AO pairs kl <= ij */
+            for (int sk = 0; sk <= si; sk++)
+                for (int sl = 0; sl <= sk; sl++) {
+                    if (q[si * nbas + sj] * q[sk * nbas + sl] < tol) continue;
+                    pair_t *ab = pp + P, *cd = pp + (size_t)sk * (sk + 1) / 2 + sl;
+                    int di = 2 * ab->la + 1, dj = 2 * ab->lb + 1, dk = 2 * cd->la + 1, dl = 2 * cd->lb + 1;
+                    /* any element with kl <= ij?  smallest kl of the block vs largest ij of the block */
+                    long ijmax = (long)(loc[si] + di - 1) * (loc[si] + di) / 2 + (loc[sj] + dj - 1);
+                    long klmin = (long)loc[sk] * (loc[sk] + 1) / 2 + loc[sl];
+                    if (klmin > ijmax) continue;
+                    nquart++;
+                    eri_cart(ab, cd, cart);
+                    double *sph = cart + QBUF;
+                    c2s_quartet(ab->la, ab->lb, cd->la, cd->lb, cart, sph, cart + 2 * QBUF);
+                    for (int a = 0; a < di; a++)
+                        for (int b = 0; b < dj; b++) {
+                            long I = loc[si] + a, J = loc[sj] + b;
+                            if (J > I) continue;
+                            long ij = I * (I + 1) / 2 + J;
+                            double *row = buf + row_off[ij];
+                            for (int c = 0; c < dk; c++)
+                                for (int d = 0; d < dl; d++) {
+                                    long K = loc[sk] + c, L = loc[sl] + d;
+                                    if (L > K) continue;
+                                    long kl = K * (K + 1) / 2 + L;
+                                    if (kl <= ij) row[kl] = sph[((a * dj + b) * dk + c) * dl + d];
+                                }
+                        }
+                }
+        }
+        free(cart);
+    }
+    free_pairs(pp, nbas);
+    free(q); free(loc);
+    return nquart;
+}
+
+void orc_jk_incore(const int *bas, int nbas, const long *row_off, const double *buf, const double *D, double *J, double *K)
+{
+    int nao = orc_nao(bas, nbas);
+    size_t nn = (size_t)nao * nao;
+    memset(J, 0, sizeof(double) * nn);
+    memset(K, 0, sizeof(double) * nn);
+#pragma omp parallel
+    {
+        double *Ja = (double *)calloc(nn, sizeof(double)), *Ka = (double *)calloc(nn, sizeof(double));
+#pragma omp for schedule(dynamic, 8)
+        for (int I = nao - 1; I >= 0; I--)
+            for (int Jx = 0; Jx <= I; Jx++) {
+                long ij = (long)I * (I + 1) / 2 + Jx;
+                if (row_off[ij] < 0) continue;
+                const double *row = buf + row_off[ij];
+                const double wij = (I == Jx) ? 0.5 : 1.0;
+                const double dij = D[(size_t)I * nao + Jx];
+                double jij = 0.0;
+                long kl = 0;
+                for (int Kx = 0; Kx <= I; Kx++) {
+                    const int lmax = (Kx == I) ? Jx : Kx;
+                    const double dik = D[(size_t)I * nao + Kx], djk = D[(size_t)Jx * nao + Kx];
+                    double kik = 0.0, kjk = 0.0;
+                    for (int Lx = 0; Lx <= lmax; Lx++, kl++) {
+                        double v = row[kl] * wij;
+                        if (Kx == Lx) v *= 0.5;
+                        if (kl == ij) v *= 0.5;
+                        jij += v * D[(size_t)Kx * nao + Lx];
+                        Ja[(size_t)Kx * nao + Lx] += v * dij;
+                        kik += v * D[(size_t)Jx * nao + Lx];
+                        Ka[(size_t)I * nao + Lx] += v * djk;
+                        kjk += v * D[(size_t)I * nao + Lx];
+                        Ka[(size_t)Jx * nao + Lx] += v * dik;
+                    }
+                    Ka[(size_t)I * nao + Kx] += kik;
+                    Ka[(size_t)Jx * nao + Kx] += kjk;
+                }
+                Ja[(size_t)I * nao + Jx] += jij;
+            }
+#pragma omp critical
+        {
+            for (size_t n = 0; n < nn; n++) { J[n] += Ja[n]; K[n] += Ka[n]; }
+        }
+        free(Ja); free(Ka);
+    }
+    for (int a = 0; a < nao; a++)
+        for (int b = 0; b <= a; b++) {
+            double js = 2.0 * (J[a * nao + b] + J[b * nao + a]);
+            double ks = K[a * nao + b] + K[b * nao + a];
+            J[a * nao + b] = J[b * nao + a] = js;
+            K[a * nao + b] = K[b * nao + a] = ks;
+        }
+}
+
+/* One shell block of J and of K by brute force over ALL ket shells (no symmetry, no screening): the full-size
+ * spot check for molecules whose complete J/K the oracle cannot afford (C60/6-31G*, ibuprofen/def2-TZVP).
+ *   Jblk[a][b] = sum_{cd} (ab|cd) D_cd   for a in shell sa, b in shell sb
+ *   Kblk[a][c] = sum_{bd} (ab|cd) D_bd   for a in shell sa, c in shell sb     (both blocks use the SAME shell pair sa, sb) */
+void orc_jk_shellblock(const int *atm, int natm, const int *bas, int nbas, const double *env, int sa, int sb,
+                       const double *D, double *Jblk, double *Kblk)
+{
+    int nao = orc_nao(bas, nbas);
+    int *loc = (int *)malloc(sizeof(int) * (nbas + 1));
+    ao_offsets(bas, nbas, loc);
+    shell_t A = get_shell(atm, bas, env, sa), B = get_shell(atm, bas, env, sb);
+    int da = 2 * A.l + 1, db = 2 * B.l + 1;
+    for (int n = 0; n < da * db; n++) { Jblk[n] = 0.0; Kblk[n] = 0.0; }
+    pair_t ab;
+    build_pair(&A, &B, &ab);
+#pragma omp parallel
+    {
+        double *cart = (double *)malloc(sizeof(double) * QBUF * 3);
+        double Jl[NSPH_MAX * NSPH_MAX] = {0}, Kl[NSPH_MAX * NSPH_MAX] = {0};
+#pragma omp for schedule(dynamic, 4) collapse(2)
+        for (int sc = 0; sc < nbas; sc++)
+            for (int sd = 0; sd < nbas; sd++) {
+                shell_t C = get_shell(atm, bas, env, sc), Dd = get_shell(atm, bas, env, sd);
+                int dc = 2 * C.l + 1, dd = 2 * Dd.l + 1;
+                double *sph = cart + QBUF;
+                pair_t cd;
+                /* J: (sa sb | sc sd) */
+                build_pair(&C, &Dd, &cd);
+                eri_cart(&ab, &cd, cart);
+                c2s_quartet(A.l, B.l, C.l, Dd.l, cart, sph, cart + 2 * QBUF);
+                for (int a = 0; a < da; a++)
+                    for (int b = 0; b < db; b++)
+                        for (int c = 0; c < dc; c++)
+                            for (int d = 0; d < dd; d++)
+                                Jl[a * db + b] += sph[((a * db + b) * dc + c) * dd + d] * D[(size_t)(loc[sc] + c) * nao + loc[sd] + d];
+                free_pair(&cd);
+                /* K: (sa sc | sb sd), contracted over the SECOND and FOURTH index */
+                pair_t ac, bd;
+                build_pair(&A, &C, &ac);
+                build_pair(&B, &Dd, &bd);
+                eri_cart(&ac, &bd, cart);
+                c2s_quartet(A.l, C.l, B.l, Dd.l, cart, sph, cart + 2 * QBUF);
+                for (int a = 0; a < da; a++)
+                    for (int c = 0; c < dc; c++)
+                        for (int b = 0; b < db; b++)
+                            for (int d = 0; d < dd; d++)
+                                Kl[a * db + b] += sph[((a * dc + c) * db + b) * dd + d] * D[(size_t)(loc[sc] + c) * nao + loc[sd] + d];
+                free_pair(&ac); free_pair(&bd);
+            }
+#pragma omp critical
+        for (int n = 0; n < da * db; n++) { Jblk[n] += Jl[n]; Kblk[n] += Kl[n]; }
+        free(cart);
+    }
+    free_pair(&ab);
+    free(loc);
 }
 
 int orc_num_threads(void)

@@ -32,6 +32,8 @@ def lib():
     if _LIB is None:
         _LIB = ctypes.CDLL(build())
         _LIB.orc_jk_direct.restype = ctypes.c_long
+        _LIB.orc_incore_layout.restype = ctypes.c_long
+        _LIB.orc_incore_fill.restype = ctypes.c_long
     return _LIB
 
 
@@ -81,11 +83,41 @@ class Oracle:
         return out
 
     def jk(self, dm, tol=1e-13):
+        if getattr(self, "_incore", None) is not None:
+            return self.jk_incore(dm)
         n = self.nao
         dm = np.ascontiguousarray(dm, dtype=np.float64)
         J, K = np.zeros((n, n)), np.zeros((n, n))
         nq = lib().orc_jk_direct(*self._args(), _p(dm), _p(J), _p(K), ctypes.c_double(tol))
         self.last_nquartets = nq
+        return J, K
+
+    def jk_shellblock(self, sa, sb, dm):
+        """(J[sa-block, sb-block], K[sa-block, sb-block]) summed over ALL other shells by brute force (full-size spot checks)."""
+        da, db = 2 * int(self.bas[sa, 1]) + 1, 2 * int(self.bas[sb, 1]) + 1
+        dm = np.ascontiguousarray(dm, dtype=np.float64)
+        J, K = np.zeros((da, db)), np.zeros((da, db))
+        lib().orc_jk_shellblock(*self._args(), int(sa), int(sb), _p(dm), _p(J), _p(K))
+        return J, K
+
+    def incore(self, tol=1e-13, stride=1, phase=0):
+        """Packed (ij|kl), ij >= kl (PySCF's cached `int2e` s8 array [MEM]); `stride` > 1 keeps only the rows of every
+        stride-th shell pair (bench.py's bounded CPU sample).  Afterwards `jk()` digests the packed array."""
+        npair = self.nao * (self.nao + 1) // 2
+        row_off = np.zeros(npair, dtype=np.int64)
+        need = lib().orc_incore_layout(_p(self.bas, ctypes.c_int), self.nbas, int(stride), int(phase), _p(row_off, ctypes.c_long))
+        buf = np.zeros(need)
+        nq = lib().orc_incore_fill(*self._args(), ctypes.c_double(tol), int(stride), int(phase), _p(row_off, ctypes.c_long), _p(buf))
+        self._incore = (row_off, buf)
+        self.incore_nquartets, self.incore_doubles = nq, need
+        return self
+
+    def jk_incore(self, dm):
+        row_off, buf = self._incore
+        n = self.nao
+        dm = np.ascontiguousarray(dm, dtype=np.float64)
+        J, K = np.zeros((n, n)), np.zeros((n, n))
+        lib().orc_jk_incore(_p(self.bas, ctypes.c_int), self.nbas, _p(row_off, ctypes.c_long), _p(buf), _p(dm), _p(J), _p(K))
         return J, K
 
     @staticmethod
@@ -133,10 +165,10 @@ def eig_gen(f, s):
     return e, Li.T @ c
 
 
-def rhf(mol, dm0=None, conv_tol=1e-9, max_cycle=50, veff_fn=None, verbose=False, jk_tol=1e-13):
+def rhf(mol, dm0=None, conv_tol=1e-9, max_cycle=50, veff_fn=None, verbose=False, jk_tol=1e-13, oracle=None):
     """Closed-shell SCF.  `veff_fn(dm) -> (vhf, e_extra_xc_minus_trace_correction)` lets the RKS oracle
-    reuse the loop; default is RHF: vhf = J - K/2."""
-    orc = Oracle(mol)
+    reuse the loop; default is RHF: vhf = J - K/2.  `oracle`: an `Oracle` to reuse (e.g. one holding in-core ERIs)."""
+    orc = oracle if oracle is not None else Oracle(mol)
     S, T, V, _ = orc.int1e()
     h = T + V
     enuc = mol.energy_nuc()

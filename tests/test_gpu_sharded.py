@@ -88,3 +88,28 @@ def test_direct_mode_streamed_tile_groups_match_resident():
     mf._stream_groups = 3
     e3 = mf.kernel()
     assert mf.converged and abs(e1 - e3) < 1e-9
+
+
+def test_direct_mode_gradient_matches_resident():
+    """in direct mode the last `mi_eri_prepare` split is a tile GROUP (rank*ng + v of nranks*ng); the
+    derivative-quartet batches must still be shared by (rank, nranks) only -- `mi_grad_eri_sharded` takes them explicitly.
+    The analytic gradient with 3 streamed tile groups equals the resident-mode gradient."""
+    import numpy as np
+    from pyscf import gto, scf, dft
+    mol = gto.Mole()
+    mol.atom = MOLECULES["h2co"]
+    mol.basis = "6-31G(d)"
+    mol.verbose = 0
+    mol.build()
+    for make in (lambda: scf.RHF(mol), lambda: dft.RKS(mol, xc="B3LYP")):
+        mf = make()
+        mf.conv_tol = 1e-11
+        mf.kernel()
+        g1 = mf.nuc_grad_method().kernel()
+        mf3 = make()
+        mf3.conv_tol = 1e-11
+        mf3._stream_groups = 3
+        mf3.kernel()
+        g3 = mf3.nuc_grad_method().kernel()
+        assert mf3.converged and np.abs(g3 - g1).max() < 1e-8, np.abs(g3 - g1).max()
+        assert np.abs(g1).max() > 1e-3
