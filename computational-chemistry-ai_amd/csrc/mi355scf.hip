@@ -3464,9 +3464,11 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
 // DGEMM (launch-latency bound at 10 us for N=114) plus an update kernel.
 //   Xc  = first ? Xp : ( |tr X2p - N| < |2 tr Xp - tr X2p - N| ? X2p : 2 Xp - X2p )   (formed on the fly)
 //   X2c = Xc * Xc^T (X is symmetric), 16x16 output tile per workgroup on v_mfma_f64_16x16x4_f64,
-//   K split over the 4 waves of the workgroup, row panels staged in LDS; traces of Xc and X2c are
-//   accumulated with atomics into trc[2] for the next launch's branch decision.
+//   K split over the 4 waves of the workgroup, row panels staged in LDS; every diagonal workgroup b writes its share of
+//   tr Xc, tr X2c to trc[2b], trc[2b+1] and the next launch adds the SP2_TRS slots in index order for its branch decision
+//   (no atomics: bit-identical on every rank of a sharded run).
 // =================================================================================================
+#define SP2_TRS 32 /* trace slots per step = max diagonal workgroups (N <= 512) */
 __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *Xp, const double *X2p, const double *trp, int first,
                                                         int n, int kpad, double target, double *Xc, double *X2c, double *trc)
 {
@@ -3478,7 +3480,11 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *Xp, const 
     const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
     // the branch decision needs the traces of the previous launch (memory-side atomics: a full-latency
     // read).  Issue it together with the panel loads and select afterwards, so the two latencies overlap.
-    const double tx = first ? 0.0 : trp[0], tx2 = first ? 0.0 : trp[1];
+    double tx = 0.0, tx2 = 0.0;
+    if (!first) {
+        const int nbd = (n + 15) / 16;
+        for (int b = 0; b < nbd; b++) { tx += trp[2 * b]; tx2 += trp[2 * b + 1]; }
+    }
     constexpr int PER = 16; // panel elements per thread per batch
     for (int base = 0; base < 16 * kpad; base += 256 * PER) {
         double xa[PER], ya[PER], xb[PER], yb[PER];
@@ -3531,13 +3537,14 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *Xp, const 
         }
         if (blockIdx.x == blockIdx.y) {
             for (int o = 32; o > 0; o >>= 1) { tr1 += __shfl_xor(tr1, o); tr2 += __shfl_xor(tr2, o); }
-            if (lane == 0) { atomicAdd(&trc[0], tr1); atomicAdd(&trc[1], tr2); }
+            if (lane == 0) { trc[2 * blockIdx.x] = tr1; trc[2 * blockIdx.x + 1] = tr2; }
         }
     }
 }
 
-// d_X (in/out), d_X2 (in if have_x2, out), d_work: 2*n*n doubles, d_tr: (nit+2)*2 doubles (device).
-// On return d_X = X_nit, d_X2 = X_nit^2 and d_tr_out[0..1] = their traces (device pointer into d_tr).
+// d_X (in/out), d_X2 (in if have_x2, out), d_work: 2*n*n doubles, d_tr: (nit+2)*2*SP2_TRS doubles (device).
+// On return d_X = X_nit, d_X2 = X_nit^2 and d_tr_out points at the 2*ceil(n/16) partial traces {tr X, tr X^2} interleaved
+// (device pointer into d_tr; the caller adds them in index order).
 extern "C" int mi_sp2_iterate(mi_ctx *c, double *d_X, double *d_X2, int nit, double n_occ, int have_x2, double *d_work,
                               double *d_tr, double **d_tr_out, void *stream)
 {
@@ -3550,22 +3557,15 @@ extern "C" int mi_sp2_iterate(mi_ctx *c, double *d_X, double *d_X2, int nit, dou
     const int nb = (n + 15) / 16;
     dim3 grid(nb, nb), block(256);
     const size_t nn = (size_t)n * n;
-    HIPCHK(hipMemsetAsync(d_tr, 0, sizeof(double) * 2 * (nit + 2), st));
+    (void)have_x2; // X^2 and the traces of the incoming X are always (re)derived by the first pass
+    constexpr int TS = 2 * SP2_TRS;
     double *cur_x = d_X, *cur_x2 = d_X2, *nxt_x = d_work, *nxt_x2 = d_work + nn;
     int slot = 0;
-    if (!have_x2) {
-        hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur_x, cur_x2, d_tr, 1, n, kpad, n_occ, nxt_x, nxt_x2, d_tr + 2 * slot);
-        std::swap(cur_x, nxt_x); std::swap(cur_x2, nxt_x2);
-    } else {
-        // traces of the incoming pair are needed for the first branch decision: recompute them with a first=1 pass
-        // on X only when absent; callers that pass have_x2 also pass valid traces in d_tr[0..1] BEFORE the memset,
-        // so re-derive them here from the matrices (cheap, one launch).
-        hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur_x, cur_x2, d_tr, 1, n, kpad, n_occ, nxt_x, nxt_x2, d_tr + 2 * slot);
-        std::swap(cur_x, nxt_x); std::swap(cur_x2, nxt_x2);
-    }
+    hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur_x, cur_x2, d_tr, 1, n, kpad, n_occ, nxt_x, nxt_x2, d_tr + TS * slot);
+    std::swap(cur_x, nxt_x); std::swap(cur_x2, nxt_x2);
     for (int it = 0; it < nit; it++) {
-        hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur_x, cur_x2, d_tr + 2 * slot, 0, n, kpad, n_occ, nxt_x, nxt_x2,
-                           d_tr + 2 * (slot + 1));
+        hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur_x, cur_x2, d_tr + TS * slot, 0, n, kpad, n_occ, nxt_x, nxt_x2,
+                           d_tr + TS * (slot + 1));
         slot++;
         std::swap(cur_x, nxt_x); std::swap(cur_x2, nxt_x2);
     }
@@ -3574,7 +3574,7 @@ extern "C" int mi_sp2_iterate(mi_ctx *c, double *d_X, double *d_X2, int nit, dou
         HIPCHK(hipMemcpyAsync(d_X, cur_x, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(d_X2, cur_x2, sizeof(double) * nn, hipMemcpyDeviceToDevice, st));
     }
-    *d_tr_out = d_tr + 2 * slot;
+    *d_tr_out = d_tr + TS * slot;
     return 0;
 }
 
@@ -3592,17 +3592,17 @@ extern "C" int mi_sp2_iterate_pingpong(mi_ctx *c, double *d_A, double *d_B, int 
     const int nb = (n + 15) / 16;
     dim3 grid(nb, nb), block(256);
     const size_t nn = (size_t)n * n;
-    HIPCHK(hipMemsetAsync(d_tr, 0, sizeof(double) * 2 * (nit + 2), st));
+    constexpr int TS = 2 * SP2_TRS;
     double *cur = d_A, *nxt = d_B;
     hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur, cur + nn, d_tr, 1, n, kpad, n_occ, nxt, nxt + nn, d_tr);
     std::swap(cur, nxt);
     for (int it = 0; it < nit; it++) {
-        hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur, cur + nn, d_tr + 2 * it, 0, n, kpad, n_occ, nxt, nxt + nn,
-                           d_tr + 2 * (it + 1));
+        hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur, cur + nn, d_tr + TS * it, 0, n, kpad, n_occ, nxt, nxt + nn,
+                           d_tr + TS * (it + 1));
         std::swap(cur, nxt);
     }
     HIPCHK(hipGetLastError());
-    *d_tr_out = d_tr + 2 * nit;
+    *d_tr_out = d_tr + TS * nit;
     *d_res = cur;
     return 0;
 }
@@ -3610,9 +3610,11 @@ extern "C" int mi_sp2_iterate_pingpong(mi_ctx *c, double *d_A, double *d_B, int 
 // =================================================================================================
 // Fused elementwise pieces of the SCF cycle (fewer launches per cycle)
 // =================================================================================================
-// F = h + J - (kscale) K (+ Vxc), and scal[0] += sum D*(h + 0.5*(J - kscale K))  [one-electron + Coulomb/exchange energy]
+// F = h + J - (kscale) K (+ Vxc), and part[block] = this block's share of sum D*(h + 0.5*(J - kscale K))  [one-electron +
+// Coulomb/exchange energy].  Partial sums in a FIXED order instead of atomics: the replicated algebra of a sharded run must
+// give bit-identical results on every rank (the caller adds the ceil(nn/256) partials in index order).
 __global__ __launch_bounds__(256) void fock_energy_kernel(const double *h, const double *J, const double *K, const double *Vxc,
-                                                          const double *D, double kscale, size_t nn, double *F, double *scal)
+                                                          const double *D, double kscale, size_t nn, double *F, double *part)
 {
     __shared__ double sh[4];
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3626,22 +3628,24 @@ __global__ __launch_bounds__(256) void fock_energy_kernel(const double *h, const
     for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = e;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&scal[0], sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+extern "C" int mi_reduce_blocks(const mi_ctx *c) { return c ? (int)(((size_t)c->nao * c->nao + 255) / 256) : -1; }
+
 extern "C" int mi_fock_energy(mi_ctx *c, const double *d_h, const double *d_J, const double *d_K, const double *d_Vxc,
-                              const double *d_D, double kscale, double *d_F, double *d_scal, void *stream)
+                              const double *d_D, double kscale, double *d_F, double *d_part, void *stream)
 {
-    if (!c || !d_h || !d_J || !d_D || !d_F || !d_scal) return fail("mi_fock_energy: null argument");
+    if (!c || !d_h || !d_J || !d_D || !d_F || !d_part) return fail("mi_fock_energy: null argument");
     size_t nn = (size_t)c->nao * c->nao;
     hipLaunchKernelGGL(fock_energy_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_h, d_J, d_K, d_Vxc,
-                       d_D, kscale, nn, d_F, d_scal);
+                       d_D, kscale, nn, d_F, d_part);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-// E = M - M^T and scal[0] += sum E^2
-__global__ __launch_bounds__(256) void commutator_norm_kernel(const double *M, int n, double *E, double *scal)
+// E = M - M^T and part[block] = this block's share of sum E^2 (fixed-order partials, see fock_energy_kernel)
+__global__ __launch_bounds__(256) void commutator_norm_kernel(const double *M, int n, double *E, double *part)
 {
     __shared__ double sh[4];
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3655,15 +3659,15 @@ __global__ __launch_bounds__(256) void commutator_norm_kernel(const double *M, i
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&scal[0], sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-extern "C" int mi_commutator_norm(mi_ctx *c, const double *d_M, double *d_E, double *d_scal, void *stream)
+extern "C" int mi_commutator_norm(mi_ctx *c, const double *d_M, double *d_E, double *d_part, void *stream)
 {
-    if (!c || !d_M || !d_E || !d_scal) return fail("mi_commutator_norm: null argument");
+    if (!c || !d_M || !d_E || !d_part) return fail("mi_commutator_norm: null argument");
     int n = c->nao;
     hipLaunchKernelGGL(commutator_norm_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_M, n, d_E,
-                       d_scal);
+                       d_part);
     HIPCHK(hipGetLastError());
     return 0;
 }

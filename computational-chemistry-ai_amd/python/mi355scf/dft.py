@@ -71,15 +71,23 @@ class RKS(RHF):
             self._log(4, f"XC grid: {self.grids.size} points (level {self.grids.level})")
 
     def nr_rks(self, dm):
-        """(N_elec, E_xc, V_xc) on device for a closed-shell density (numint.nr_rks [MEM])."""
+        """(N_elec, E_xc, V_xc, hyb) on device for a closed-shell density (numint.nr_rks [MEM]): this rank's share of the
+        grid; sharded callers all-reduce."""
+        n = self.engine.nao
+        vmat = torch.zeros(n, n, dtype=torch.float64, device=self.engine.device)
+        tail = torch.zeros(2, dtype=torch.float64, device=self.engine.device)
+        hyb = self._nr_rks_raw(dm, vmat, tail)
+        return tail[0], tail[1], vmat + vmat.T, hyb
+
+    def _nr_rks_raw(self, dm, vmat, tail):
+        """Accumulate the UNsymmetrised XC matrix (V_xc = vmat + vmat^T) into `vmat` and [N_elec, E_xc] into `tail` -- views of
+        a caller-owned (zeroed) buffer, e.g. the fused all-reduce buffer of `_fock_energy`.  Returns the exact-exchange
+        fraction of the functional."""
         eng = self.engine
         hyb, terms, gga = parse_xc(self.xc)
         n = eng.nao
         coords, weights = self.grids.coords, self.grids.weights
         ng = coords.shape[0]
-        vmat = torch.zeros(n, n, dtype=torch.float64, device=eng.device)
-        nelec = torch.zeros((), dtype=torch.float64, device=eng.device)
-        exc = torch.zeros((), dtype=torch.float64, device=eng.device)
         lo, hi = self._grid_range(ng)
         # grid block: as large as a ~1.5 GB working set allows (fewer launches for small molecules), at least grid_block
         B = max(self.grid_block, int(1.5e9 / (48.0 * n)) // 1024 * 1024)
@@ -96,12 +104,11 @@ class RKS(RHF):
             C = dm @ ao[0]
             rho = eng.xc_rho(ao, C, deriv=1 if gga else 0)
             e, wv = eng.xc_eval(terms, rho, w, gga)
-            nelec += torch.dot(w, rho[0])
-            exc += torch.dot(w, e)
+            tail[0] += torch.dot(w, rho[0])
+            tail[1] += torch.dot(w, e)
             aow = eng.xc_aow(ao, wv, gga)
             eng.xc_vmat(ao[0], aow, vmat)      # vmat += ao0 . aow^T  (split-K FP64 MFMA kernel)
-        vmat = vmat + vmat.T
-        return nelec, exc, vmat, hyb
+        return hyb
 
     def _ao_cache_for(self, nao, npts, ncomp):
         """AO values on this rank's grid points are kept resident between SCF cycles when they fit in a quarter
@@ -146,19 +153,33 @@ class RKS(RHF):
             if self.grids.atom_of is not None:
                 self.grids.atom_of = self.grids.atom_of[keep.cpu().numpy()]
 
-    def _fock_energy(self, dm, scal):
+    def _fock_energy(self, dm, part):
+        """Kohn-Sham Fock matrix with ONE collective per build: this rank's partial J, K (tile-run
+        shard) and unsymmetrised V_xc, N_elec, E_xc (grid shard) live in one flat buffer [J | K | Vxc | N | Exc] that is
+        all-reduced once."""
         if not getattr(self, "_pruned", False):
             self._prune_small_rho_grids(dm)
-        nelec, exc, vxc, hyb = self._xc_reduced(dm)
-        self._nelec_grid = nelec
-        if abs(hyb) > 1e-12:
-            J, K = self._jk(dm)
-        else:
-            J, K = self._jk(dm, with_k=False)[0], None
+        eng = self.engine
+        n = eng.nao
+        nn = n * n
+        hyb = parse_xc(self.xc)[0]
+        with_k = abs(hyb) > 1e-12
+        nmat = 3 if with_k else 2
+        buf = torch.zeros(nmat * nn + 2, dtype=torch.float64, device=eng.device)
+        J = buf[:nn].view(n, n)
+        K = buf[nn:2 * nn].view(n, n) if with_k else None
+        V = buf[(nmat - 1) * nn:nmat * nn].view(n, n)
+        tail = buf[nmat * nn:]
+        self._nr_rks_raw(dm, V, tail)
+        self._jk_into(dm, J, K)
+        if self._nranks > 1:
+            from . import parallel
+            parallel.all_reduce_sum(buf, self._pg)
+        vxc = V + V.T
+        self._nelec_grid = tail[0]
         F = torch.empty_like(J)
-        self.engine.fock_energy(self._h1, J, K, vxc, dm, 0.5 * hyb, F, scal)
-        scal += exc
-        return F
+        eng.fock_energy(self._h1, J, K, vxc, dm, 0.5 * hyb, F, part)
+        return F, tail[1:2]
 
     def _xc_reduced(self, dm):
         nelec, exc, vxc, hyb = self.nr_rks(dm)

@@ -93,6 +93,7 @@ def lib():
         L.mi_eri_get_memory.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.mi_eri_read_quartet.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
         L.mi_schwarz_get.argtypes = [vp, dp]
+        L.mi_reduce_blocks.argtypes = [vp]
         L.mi_plan_shards.argtypes = [ctypes.c_int, dp, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
                                      ctypes.POINTER(ctypes.c_int64)]
         L.mi_fock_energy.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp]
@@ -231,10 +232,20 @@ class Engine:
         return {k: getattr(s, k) for k, _ in _Stats._fields_}
 
     # --- rows a5, a6 ---------------------------------------------------------------------------
-    def get_jk(self, dm, with_j=True, with_k=True):
+    def get_jk(self, dm, with_j=True, with_k=True, out_j=None, out_k=None):
+        """J, K for one [N,N] or several [n_dm,N,N] densities.  `out_j` / `out_k`: contiguous device tensors of the result
+        shape to write into (views of a caller-owned buffer, e.g. the fused [J|K|Vxc|N|Exc] all-reduce buffer of RKS)."""
         if not self.eri_ready:
             self.prepare_eri()
         dm = torch.as_tensor(dm, dtype=torch.float64, device=self.device).contiguous()
+        if out_j is not None or out_k is not None:
+            assert (out_j is None or (out_j.is_contiguous() and out_j.shape == dm.shape)) and \
+                   (out_k is None or (out_k.is_contiguous() and out_k.shape == dm.shape))
+            with torch.cuda.device(self.device):
+                _check(lib().mi_build_jk(self._h, dm.data_ptr(), 1 if dm.dim() == 2 else dm.shape[0],
+                                         out_j.data_ptr() if (with_j and out_j is not None) else None,
+                                         out_k.data_ptr() if (with_k and out_k is not None) else None, self._stream()))
+            return (out_j if with_j else None), (out_k if with_k else None)
         squeeze = dm.dim() == 2
         if squeeze:
             dm = dm.unsqueeze(0)
@@ -345,7 +356,8 @@ class Engine:
         _check(lib().mi_sp2_update(self._h, X.data_ptr(), X2.data_ptr(), float(nocc), out.data_ptr(), self._stream()))
 
     def sp2_iterate(self, X, X2, nit, nocc, work, tr):
-        """Fused SP2 passes (N <= 512); returns the offset (in doubles) inside `tr` of {tr X, tr X^2}."""
+        """Fused SP2 passes (N <= 512); returns the offset (in doubles) inside `tr` of the 2*ceil(N/16) interleaved partial
+        traces {tr X, tr X^2} (add them in index order: `sp2_traces`)."""
         out = ctypes.c_void_p()
         _check(lib().mi_sp2_iterate(self._h, X.data_ptr(), X2.data_ptr(), int(nit), float(nocc), 0, work.data_ptr(),
                                     tr.data_ptr(), ctypes.byref(out), self._stream()))
@@ -358,13 +370,21 @@ class Engine:
                                              ctypes.byref(out), ctypes.byref(res), self._stream()))
         return (A if res.value == A.data_ptr() else B), (out.value - tr.data_ptr()) // 8
 
-    def fock_energy(self, h, J, K, Vxc, D, kscale, F, scal):
+    @property
+    def reduce_blocks(self):
+        """Number of fixed-order partial sums `fock_energy` / `commutator_norm` write (ceil(nao^2 / 256))."""
+        return (self.nao * self.nao + 255) // 256
+
+    def fock_energy(self, h, J, K, Vxc, D, kscale, F, part):
+        """F = h + J - kscale K (+ Vxc); part[reduce_blocks] = partial sums of E_elec (add them in index order)."""
+        assert part.numel() == self.reduce_blocks and part.is_contiguous()
         _check(lib().mi_fock_energy(self._h, h.data_ptr(), J.data_ptr(), K.data_ptr() if K is not None else None,
                                     Vxc.data_ptr() if Vxc is not None else None, D.data_ptr(), float(kscale), F.data_ptr(),
-                                    scal.data_ptr(), self._stream()))
+                                    part.data_ptr(), self._stream()))
 
-    def commutator_norm(self, M, E, scal):
-        _check(lib().mi_commutator_norm(self._h, M.data_ptr(), E.data_ptr(), scal.data_ptr(), self._stream()))
+    def commutator_norm(self, M, E, part):
+        assert part.numel() == self.reduce_blocks and part.is_contiguous()
+        _check(lib().mi_commutator_norm(self._h, M.data_ptr(), E.data_ptr(), part.data_ptr(), self._stream()))
 
     # --- row a10 -------------------------------------------------------------------------------
     def diis_errvec(self, sdf, out):

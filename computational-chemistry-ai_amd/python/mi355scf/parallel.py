@@ -1,14 +1,25 @@
 """Multi-GPU plumbing: one process per GPU, `torch.distributed` over RCCL/xGMI.
 
-The resident-ERI tile runs are dealt round-robin to ranks inside `mi_eri_prepare(rank, nranks)` -- no
-ERI ever crosses xGMI.  Each Fock build ends in ONE all-reduce of a fused FP64 buffer ([J|K], or
-[Vxc|N_elec|E_xc] for the grid-sharded XC part); D is replicated, diagonalisation/DIIS are replicated.
+The resident-ERI tile runs are dealt to ranks longest-processing-time first by bytes inside
+`mi_eri_prepare(rank, nranks)` -- no ERI ever crosses xGMI.  Each Fock build ends in ONE all-reduce of ONE fused FP64
+buffer ([J|K] for HF, [J|K|Vxc|N_elec|E_xc] for Kohn-Sham with the grid sharded too); D is replicated, the
+purification / diagonalisation / DIIS algebra is replicated and -- being free of atomics (fixed-order partial sums) --
+bit-identical on every rank, so no control-scalar broadcast is needed inside the SCF loop.
 With the `gloo` backend (CPU tests; or two ranks sharing one GPU) tensors are staged through host memory.
 """
 import os
 
 import torch
 import torch.distributed as dist
+
+
+# collectives issued by this process (world > 1 only): lets the tests assert "one all-reduce, zero broadcasts per SCF cycle"
+STATS = {"all_reduce": 0, "broadcast": 0, "all_reduce_bytes": 0}
+
+
+def reset_stats():
+    for k in STATS:
+        STATS[k] = 0
 
 
 def init(backend=None, device=None):
@@ -32,6 +43,8 @@ def all_reduce_sum(t, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
     backend = dist.get_backend(group)
+    STATS["all_reduce"] += 1
+    STATS["all_reduce_bytes"] += t.numel() * t.element_size()
     if backend == "gloo" and t.is_cuda:
         h = t.cpu()
         dist.all_reduce(h, group=group)
@@ -68,6 +81,7 @@ def broadcast0(t, group=None):
     test must not let one rank leave a loop whose body contains a collective."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
+    STATS["broadcast"] += 1
     if dist.get_backend(group) == "gloo" and t.is_cuda:
         h = t.cpu()
         dist.broadcast(h, src=0, group=group)

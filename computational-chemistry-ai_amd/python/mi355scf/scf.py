@@ -141,6 +141,7 @@ class SCF:
     _sp2_validated = False   # True once an iteration count has passed the checked path for this Fock spectrum
     sp2_fused_max = 272  # measured (ping-pong kernel, no copies): fused wins at N=114 and N=264 (1.73 -> 1.60 ms/cycle), rocBLAS at N=300
     _spin_restricted = True
+    sync_control = False   # sharded runs: broadcast rank 0's control scalars every cycle (not needed: deterministic reductions)
     level_shift = 0.0    # Hartree; virtual-orbital shift applied to the Fock matrix that is diagonalised / purified
 
     def __init__(self, mol):
@@ -274,9 +275,21 @@ class SCF:
             parallel.all_reduce_fused([x for x in (J, K) if x is not None], self._pg)
         return J, K
 
+    def _jk_into(self, dm, J, K):
+        """This rank's PARTIAL J (and K unless None) written into caller-owned views, no collective: the caller all-reduces
+        the buffer the views live in (Kohn-Sham: one fused [J|K|Vxc|N|Exc] collective per Fock build)."""
+        if self._stream_groups > 1:
+            j, k = self._jk_streamed(dm, True, K is not None)
+            J.copy_(j)
+            if K is not None:
+                K.copy_(k)
+        else:
+            self.engine.get_jk(dm, True, K is not None, out_j=J, out_k=K)
+
     def get_jk(self, mol=None, dm=None, hermi=1, with_j=True, with_k=True, **kw):
         if dm is None:
             dm = self.make_rdm1()
+        self._setup_once()   # integrals + resident ERI tiles (or the direct-mode fallback when the store does not fit)
         J, K = self._jk(dm, with_j, with_k)
         return (J.cpu().numpy() if with_j else None), (K.cpu().numpy() if with_k else None)
 
@@ -286,16 +299,24 @@ class SCF:
         vhf = J - 0.5 * K
         return vhf, 0.5 * torch.sum(dm * vhf)
 
-    def _fock_energy(self, dm, scal):
-        """F = h + veff(D) on device and scal[0] += E_elec(D) (fused kernel).  Overridden by RKS."""
+    def _fock_energy(self, dm, part):
+        """F = h + veff(D) on device; `part` receives the fixed-order partial sums of E_elec(D) (fused kernel).  Returns
+        (F, extra): `extra` is a one-element device tensor to add to the energy (E_xc) or None.  Overridden by RKS."""
         J, K = self._jk(dm)
         F = torch.empty_like(J)
-        self.engine.fock_energy(self._h1, J, K, None, dm, 0.5, F, scal)
-        return F
+        self.engine.fock_energy(self._h1, J, K, None, dm, 0.5, F, part)
+        return F, None
+
+    @staticmethod
+    def _sp2_traces(tr_host):
+        """(tr X, tr X^2) from the interleaved partial traces of the fused SP2 kernel (or a plain pair), added in index order."""
+        t = np.asarray(tr_host, dtype=np.float64).reshape(-1, 2)
+        return float(t[:, 0].sum()), float(t[:, 1].sum())
 
     def get_veff(self, mol=None, dm=None, **kw):
         if dm is None:
             dm = self.make_rdm1()
+        self._setup_once()
         d = torch.as_tensor(np.asarray(dm), dtype=torch.float64, device=self.engine.device)
         return self._veff(d)[0].cpu().numpy()
 
@@ -353,13 +374,14 @@ class SCF:
         ws = getattr(self, "_sp2f", None)
         if ws is None or ws["X"].shape[0] != n:
             mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
-            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2 * n))
+            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(64 * 80), b=mk(2 * n))
         nit = min(getattr(self, "_sp2_iters", 24), 72)
         target = float(nocc)
+        nbd = (n + 15) // 16
         for attempt in range(5):
             eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
             off = eng.sp2_iterate(ws["X"], ws["X2"], nit, target, ws["work"], ws["tr"])
-            tr = ws["tr"][off:off + 2].cpu()
+            tr = self._sp2_traces(ws["tr"][off:off + 2 * nbd].cpu().numpy())
             err = float(tr[0] - tr[1])
             if abs(err) < self.sp2_tol and abs(float(tr[0]) - target) < 1e-8:
                 self._sp2_iters = nit
@@ -377,7 +399,7 @@ class SCF:
         ws = getattr(self, "_sp2f", None)
         if ws is None or ws["X"].shape[0] != n:
             mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
-            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(2 * 80), b=mk(2 * n))
+            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(64 * 80), b=mk(2 * n))
         nit = min(self._sp2_iters, 76)
         if n <= self.sp2_fused_max and self.sp2_fused:
             pp = ws.get("pp")
@@ -386,7 +408,7 @@ class SCF:
                                  torch.empty(2, n, n, dtype=torch.float64, device=fo.device))
             eng.sp2_init(fo.contiguous(), pp[0][0], ws["b"])
             res, off = eng.sp2_iterate_pingpong(pp[0], pp[1], nit, float(nocc), ws["tr"])
-            return 2.0 * res[0], ws["tr"][off:off + 2]
+            return 2.0 * res[0], ws["tr"][off:off + 2 * ((n + 15) // 16)]   # interleaved partial traces
         eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
         # larger N: rocBLAS DGEMM + fused update kernel per step, still without a host sync
         buf = getattr(self, "_sp2_buf", None)
@@ -466,8 +488,9 @@ class SCF:
         (F', e) into the DIIS history and fetches all scalars of the cycle with ONE device-to-host copy."""
         Li, L, h1 = self._Linv, self._L, self._h1
         dm = dm.contiguous()
-        scal = torch.zeros(2, dtype=torch.float64, device=dm.device)   # [E_elec, |[F',D']|^2]
-        fock = self._fock_energy(dm, scal[0:1])
+        nb = self.engine.reduce_blocks
+        part = torch.empty(2 * nb, dtype=torch.float64, device=dm.device)   # partial sums of [E_elec | |[F',D']|^2]
+        fock, extra = self._fock_energy(dm, part[:nb])
         # PySCF feeds CDIIS only from cycle `diis_start_cycle` on [MEM]: the initial-guess Fock is not stored.  When it is
         # stored, the two GEMM chains write F' and the error vector straight into the history slot (no device copies).
         diis = st["diis"]
@@ -476,7 +499,7 @@ class SCF:
         fo = torch.matmul(Li @ fock, Li.T, out=diis.F[slot]) if keep else Li @ fock @ Li.T
         m = fo @ st["dmo"]
         eo = torch.empty_like(m)
-        self.engine.commutator_norm(m, eo, scal[1:2])  # eo = [F', D'] and its squared norm
+        self.engine.commutator_norm(m, eo, part[nb:])  # eo = [F', D'] and the partial sums of its squared norm
         # e_ao = F D S - S D F = L [F', D'] L^T  (PySCF's CDIIS error vector [MEM])
         if keep:
             torch.matmul(L @ eo, L.T, out=diis.E[slot])
@@ -485,19 +508,30 @@ class SCF:
             nd = 0
         n = fo.shape[0]
         nvo = max((n - st["nocc"]) * st["nocc"], 1)
-        parts = ([st["diis"].dots_dev[:nd]] if nd else []) + [scal] + ([sp2_tr] if sp2_tr is not None else [])
-        packed = torch.cat(parts) if len(parts) > 1 else scal
-        if self._nranks > 1:
+        parts = ([st["diis"].dots_dev[:nd]] if nd else []) + [part] + ([extra.reshape(1)] if extra is not None else []) \
+            + ([sp2_tr] if sp2_tr is not None else [])
+        packed = torch.cat(parts) if len(parts) > 1 else part
+        # Sharded runs: every rank holds the same all-reduced J/K(/Vxc) and the replicated algebra above is free of atomics
+        # (fixed-order partial sums), so these scalars are bit-identical on all ranks and steer identical control flow --
+        # no broadcast.  `sync_control = True` restores the round-1 broadcast of rank 0's copy (debugging aid).
+        if self._nranks > 1 and self.sync_control:
             from . import parallel
-            parallel.broadcast0(packed, self._pg)     # identical control flow on every rank
+            parallel.broadcast0(packed, self._pg)
         vals = packed.cpu().numpy()                    # the cycle's only host sync
+        pos = nd
+        e_el = float(vals[pos:pos + nb].sum())         # numpy's pairwise sum: the same order on every rank
+        c2 = float(vals[pos + nb:pos + 2 * nb].sum())
+        pos += 2 * nb
+        if extra is not None:
+            e_el += float(vals[pos])
+            pos += 1
         if sp2_tr is not None:
-            trx, trx2 = vals[-2], vals[-1]
+            trx, trx2 = self._sp2_traces(vals[pos:])
             if not (abs(trx - trx2) < self.sp2_tol and abs(trx - nocc) < 1e-8):
                 return False
-        e_tot = float(vals[nd]) + st["enuc"]
+        e_tot = e_el + st["enuc"]
         # |g| = |2 F_vo| = |[F',D']|_F / sqrt(2), normalised by sqrt(n_vo) like PySCF's get_grad norm [MEM]
-        gnorm = float(np.sqrt(max(vals[nd + 1], 0.0))) / np.sqrt(2.0) / np.sqrt(nvo)
+        gnorm = float(np.sqrt(max(c2, 0.0))) / np.sqrt(2.0) / np.sqrt(nvo)
         st.update(dm=dm, vhf=fock - h1, fo=fo, dots=vals[:nd], e_tot=e_tot, gnorm=gnorm,
                   de=(e_tot - e_last) if e_last is not None else 0.0)
         return True

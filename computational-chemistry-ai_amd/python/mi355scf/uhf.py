@@ -146,8 +146,11 @@ class UHF(SCF):
         enuc = mol.energy_nuc()
         conv_tol = self.conv_tol
         conv_tol_grad = self.conv_tol_grad if self.conv_tol_grad is not None else np.sqrt(conv_tol)
+        # sharded runs: the all-reduced J/K(/Vxc) are identical on every rank and the replicated algebra below is made of
+        # deterministic library reductions, so the ranks stay bit-identical without broadcasting control scalars;
+        # `sync_control = True` restores the round-1 broadcast of rank 0's Gram row / scalars (debugging aid)
         sync = None
-        if self._nranks > 1:
+        if self._nranks > 1 and self.sync_control:
             from . import parallel
             sync = lambda t: parallel.broadcast0(t, self._pg)
         diis = PairDIIS(self.diis_space, sync)
@@ -214,9 +217,8 @@ class UHF(SCF):
             # |g| = |F_vo| of both spins = |[F', D']|_F / sqrt(2) in the orthonormal basis (D' is a projector)
             eo = torch.stack([Li @ err[s_] @ Li.T for s_ in range(2)])
             ctrl = torch.stack([e_el.reshape(()), torch.sum(eo * eo)])
-            if self._nranks > 1:   # identical control flow on every rank (replicated FP64 work may differ in the last bits)
-                from . import parallel
-                parallel.broadcast0(ctrl, self._pg)
+            if sync is not None:
+                sync(ctrl)
             ctrl = ctrl.cpu().numpy()
             e_new = float(ctrl[0]) + enuc
             gnorm = float(np.sqrt(max(ctrl[1], 0.0) / 2.0)) / np.sqrt(nvo)

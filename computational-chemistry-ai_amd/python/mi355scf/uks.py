@@ -45,15 +45,21 @@ class UKS(UHF):
     _grid_range = RKS._grid_range
 
     def nr_uks(self, dm):
-        """((N_alpha, N_beta), E_xc, V_xc[2,N,N], hyb) on device for the spin densities dm[2,N,N] (numint.nr_uks [MEM])."""
+        """((N_alpha, N_beta), E_xc, V_xc[2,N,N], hyb) on device for the spin densities dm[2,N,N] (numint.nr_uks [MEM]): this
+        rank's share of the grid; sharded callers all-reduce."""
+        n = self.engine.nao
+        vmat = torch.zeros(2, n, n, dtype=torch.float64, device=self.engine.device)
+        tail = torch.zeros(3, dtype=torch.float64, device=self.engine.device)
+        hyb = self._nr_uks_raw(dm, vmat, tail)
+        return tail[:2], tail[2], vmat + vmat.transpose(1, 2), hyb
+
+    def _nr_uks_raw(self, dm, vmat, tail):
+        """Unsymmetrised V_xc,s into `vmat[2,N,N]`, [N_alpha, N_beta, E_xc] into `tail` (views of a zeroed caller buffer)."""
         eng = self.engine
         hyb, terms, gga = parse_xc(self.xc)
         n = eng.nao
         coords, weights = self.grids.coords, self.grids.weights
         ng = coords.shape[0]
-        vmat = torch.zeros(2, n, n, dtype=torch.float64, device=eng.device)
-        nelec = torch.zeros(2, dtype=torch.float64, device=eng.device)
-        exc = torch.zeros((), dtype=torch.float64, device=eng.device)
         lo, hi = self._grid_range(ng)
         B = max(self.grid_block, int(1.5e9 / (64.0 * n)) // 1024 * 1024)
         cache = self._ao_cache_for(n, hi - lo, 4 if gga else 1)
@@ -68,31 +74,47 @@ class UKS(UHF):
                     cache.append(ao)
             rho = [eng.xc_rho(ao, dm[s_] @ ao[0], deriv=1 if gga else 0) for s_ in range(2)]
             e, wva, wvb = eng.xc_eval_spin(terms, rho[0], rho[1], w, gga)
-            nelec[0] += torch.dot(w, rho[0][0])
-            nelec[1] += torch.dot(w, rho[1][0])
-            exc += torch.dot(w, e)
+            tail[0] += torch.dot(w, rho[0][0])
+            tail[1] += torch.dot(w, rho[1][0])
+            tail[2] += torch.dot(w, e)
             for s_, wv in ((0, wva), (1, wvb)):
                 eng.xc_vmat(ao[0], eng.xc_aow(ao, wv, gga), vmat[s_])
-        vmat = vmat + vmat.transpose(1, 2)
-        return nelec, exc, vmat, hyb
+        return hyb
 
     def _fock_pair(self, dm):
-        nelec, exc, vxc, hyb = self.nr_uks(dm)
+        """One collective per Fock build: [J(2) | K(2) | Vxc(2) | N_alpha N_beta E_xc] partial sums in one flat buffer."""
+        eng = self.engine
+        n = eng.nao
+        nn = n * n
+        hyb = parse_xc(self.xc)[0]
+        with_k = abs(hyb) > 1e-12
+        nj = 2 if with_k else 1          # pure functionals: one J build for the total density
+        nk = 2 if with_k else 0
+        buf = torch.zeros((nj + nk + 2) * nn + 3, dtype=torch.float64, device=eng.device)
+        J = buf[:nj * nn].view(nj, n, n)
+        K = buf[nj * nn:(nj + nk) * nn].view(2, n, n) if with_k else None
+        V = buf[(nj + nk) * nn:(nj + nk + 2) * nn].view(2, n, n)
+        tail = buf[(nj + nk + 2) * nn:]
+        self._nr_uks_raw(dm, V, tail)
+        D = dm[0] + dm[1]
+        if with_k:
+            self._jk_into(dm.contiguous(), J, K)
+            Jt = J[0] + J[1]
+        else:
+            self._jk_into(D.contiguous(), J[0], None)
+            Jt = J[0]
         if self._nranks > 1:
             from . import parallel
-            exc = exc.reshape(1)
-            parallel.all_reduce_fused([vxc, nelec, exc], self._pg)
-            exc = exc[0]
-        self._nelec_grid = nelec
+            parallel.all_reduce_sum(buf, self._pg)
+            Jt = J[0] + J[1] if with_k else J[0]
+        vxc = V + V.transpose(1, 2)
+        self._nelec_grid = tail[:2]
+        exc = tail[2]
         h1 = self._h1.unsqueeze(0)
-        D = dm[0] + dm[1]
-        if abs(hyb) > 1e-12:
-            J, K = self._jk(dm)
-            Jt = J[0] + J[1]
+        if with_k:
             F = h1 + Jt.unsqueeze(0) + vxc - hyb * K
             e = torch.sum(D * self._h1) + 0.5 * torch.sum(D * Jt) - 0.5 * hyb * torch.sum(dm * K) + exc
         else:
-            Jt = self._jk(D, with_k=False)[0]
             F = h1 + Jt.unsqueeze(0) + vxc
             e = torch.sum(D * self._h1) + 0.5 * torch.sum(D * Jt) + exc
         return F, e

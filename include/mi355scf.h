@@ -143,8 +143,10 @@ int mi_sp2_update(mi_ctx *ctx, double *d_X, const double *d_X2, double n_occ, do
                   void *stream);
 
 /* Fused SP2 for N <= 512: one launch per step (X*X on v_mfma_f64_16x16x4_f64 + branch + update + traces).
- * d_X holds X0 (or a previous iterate), d_X2 receives X^2; d_work: 2*n*n doubles; d_tr: 2*(nit+2) doubles.
- * Runs one squaring pass plus `nit` update+square passes; *d_tr_out points at {tr X, tr X^2} (device). */
+ * d_X holds X0 (or a previous iterate), d_X2 receives X^2; d_work: 2*n*n doubles; d_tr: 64*(nit+2) doubles.
+ * Runs one squaring pass plus `nit` update+square passes; *d_tr_out points at ceil(n/16) interleaved PARTIAL traces
+ * {tr X, tr X^2} (device); their sums in index order are the traces -- fixed-order partial sums instead of atomics, so that
+ * the replicated algebra of a sharded run is bit-identical on every rank (no control-scalar broadcast needed). */
 int mi_sp2_iterate(mi_ctx *ctx, double *d_X, double *d_X2, int nit, double n_occ, int have_x2,
                    double *d_work, double *d_tr, double **d_tr_out, void *stream);
 /* Same passes on two caller-owned [X | X2] buffers without the final copy; *d_res = the buffer holding the result. */
@@ -152,11 +154,13 @@ int mi_sp2_iterate_pingpong(mi_ctx *ctx, double *d_A, double *d_B, int nit, doub
                             double **d_res, void *stream);
 
 /* Fused elementwise pieces of one SCF cycle (rows a11/a12: get_fock + energy_elec, orbital-gradient norm):
- * mi_fock_energy: F = h + J - kscale*K (+Vxc); *d_scal += sum D*(h + (J - kscale*K)/2).  d_K, d_Vxc may be NULL.
- * mi_commutator_norm: E = M - M^T; *d_scal += |E|_F^2.   d_scal must be zeroed by the caller. */
+ * mi_fock_energy: F = h + J - kscale*K (+Vxc); d_part[b] = block b's share of sum D*(h + (J - kscale*K)/2).  d_K, d_Vxc may be NULL.
+ * mi_commutator_norm: E = M - M^T; d_part[b] = block b's share of |E|_F^2.
+ * d_part has mi_reduce_blocks(ctx) = ceil(nao^2/256) entries; the caller adds them in index order (deterministic). */
+int mi_reduce_blocks(const mi_ctx *ctx);
 int mi_fock_energy(mi_ctx *ctx, const double *d_h, const double *d_J, const double *d_K, const double *d_Vxc,
-                   const double *d_D, double kscale, double *d_F, double *d_scal, void *stream);
-int mi_commutator_norm(mi_ctx *ctx, const double *d_M, double *d_E, double *d_scal, void *stream);
+                   const double *d_D, double kscale, double *d_F, double *d_part, void *stream);
+int mi_commutator_norm(mi_ctx *ctx, const double *d_M, double *d_E, double *d_part, void *stream);
 
 /* ---- DFT -------------------------------------------------------------- */
 

@@ -742,14 +742,20 @@ void orc_jk_incore(const int *bas, int nbas, const long *row_off, const double *
     size_t nn = (size_t)nao * nao;
     memset(J, 0, sizeof(double) * nn);
     memset(K, 0, sizeof(double) * nn);
+    /* the rows present (all of them, or bench.py's sample), longest first, dealt dynamically to the threads */
+    long npair_ao = (long)nao * (nao + 1) / 2, nrows = 0;
+    int *rowI = (int *)malloc(sizeof(int) * npair_ao), *rowJ = (int *)malloc(sizeof(int) * npair_ao);
+    for (int I = nao - 1; I >= 0; I--)
+        for (int Jx = I; Jx >= 0; Jx--)
+            if (row_off[(long)I * (I + 1) / 2 + Jx] >= 0) { rowI[nrows] = I; rowJ[nrows] = Jx; nrows++; }
 #pragma omp parallel
     {
         double *Ja = (double *)calloc(nn, sizeof(double)), *Ka = (double *)calloc(nn, sizeof(double));
-#pragma omp for schedule(dynamic, 8)
-        for (int I = nao - 1; I >= 0; I--)
-            for (int Jx = 0; Jx <= I; Jx++) {
+#pragma omp for schedule(dynamic, 16)
+        for (long r = 0; r < nrows; r++) {
+            {
+                const int I = rowI[r], Jx = rowJ[r];
                 long ij = (long)I * (I + 1) / 2 + Jx;
-                if (row_off[ij] < 0) continue;
                 const double *row = buf + row_off[ij];
                 const double wij = (I == Jx) ? 0.5 : 1.0;
                 const double dij = D[(size_t)I * nao + Jx];
@@ -775,12 +781,14 @@ void orc_jk_incore(const int *bas, int nbas, const long *row_off, const double *
                 }
                 Ja[(size_t)I * nao + Jx] += jij;
             }
+        }
 #pragma omp critical
         {
             for (size_t n = 0; n < nn; n++) { J[n] += Ja[n]; K[n] += Ka[n]; }
         }
         free(Ja); free(Ka);
     }
+    free(rowI); free(rowJ);
     for (int a = 0; a < nao; a++)
         for (int b = 0; b <= a; b++) {
             double js = 2.0 * (J[a * nao + b] + J[b * nao + a]);
