@@ -221,7 +221,16 @@ class SCF:
         eng = self.engine
         t0 = time.time()
         S, T, V = eng.int1e()
-        self._S, self._h1 = S, T + V
+        h1 = T + V
+        if self._nranks > 1:
+            # one-off per geometry (not per cycle): rank 0's one-electron matrices become everybody's.  V is accumulated with
+            # FP64 atomics (one slice per nucleus), so replicated copies differ in the last bits; everything downstream in the
+            # SCF loop is deterministic and stays bit-identical across ranks only if it starts from identical inputs.
+            from . import parallel
+            hs = torch.stack([S, h1])
+            parallel.broadcast0(hs, self._pg)
+            S, h1 = hs[0].contiguous(), hs[1].contiguous()
+        self._S, self._h1 = S, h1
         L = torch.linalg.cholesky(S)
         self._L = L
         self._Linv = torch.linalg.solve_triangular(L, torch.eye(eng.nao, dtype=torch.float64, device=eng.device), upper=False)
@@ -478,6 +487,9 @@ class SCF:
         if dm0 is None:
             dm0 = self.get_init_guess()
         dm = torch.as_tensor(np.asarray(dm0), dtype=torch.float64, device=eng.device).contiguous()
+        if self._nranks > 1:   # one-off: identical starting density on every rank (the atomic guess is built with atomics per rank)
+            from . import parallel
+            parallel.broadcast0(dm, self._pg)
         st = {"nocc": mol.nelectron // 2, "enuc": mol.energy_nuc(), "cycle": 0, "diis": DeviceDIIS(eng, self.diis_space)}
         st["dmo"] = self._L.T @ dm @ self._L
         self._after_density(st, dm, e_last=None, next_cycle=0)
@@ -489,6 +501,7 @@ class SCF:
         Li, L, h1 = self._Linv, self._L, self._h1
         dm = dm.contiguous()
         nb = self.engine.reduce_blocks
+        self.n_fock_builds = getattr(self, "n_fock_builds", 0) + 1
         part = torch.empty(2 * nb, dtype=torch.float64, device=dm.device)   # partial sums of [E_elec | |[F',D']|^2]
         fock, extra = self._fock_energy(dm, part[:nb])
         # PySCF feeds CDIIS only from cycle `diis_start_cycle` on [MEM]: the initial-guess Fock is not stored.  When it is

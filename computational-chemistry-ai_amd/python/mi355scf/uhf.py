@@ -93,6 +93,7 @@ class UHF(SCF):
     # --- Fock pieces ----------------------------------------------------------------------------
     def _fock_pair(self, dm):
         """(F[2,N,N], E_elec) on device for the spin densities dm[2,N,N].  Overridden by UKS."""
+        self.n_fock_builds = getattr(self, "n_fock_builds", 0) + 1
         J, K = self._jk(dm)
         Jt = J[0] + J[1]
         F = self._h1.unsqueeze(0) + Jt.unsqueeze(0) - K
@@ -143,6 +144,9 @@ class UHF(SCF):
             ne = max(na + nb, 1)
             dm0 = np.stack([dm0 * (na / ne), dm0 * (nb / ne)])
         dm = torch.as_tensor(dm0, dtype=torch.float64, device=eng.device).contiguous()
+        if self._nranks > 1:   # one-off: identical starting density on every rank (see SCF._start)
+            from . import parallel
+            parallel.broadcast0(dm, self._pg)
         enuc = mol.energy_nuc()
         conv_tol = self.conv_tol
         conv_tol_grad = self.conv_tol_grad if self.conv_tol_grad is not None else np.sqrt(conv_tol)

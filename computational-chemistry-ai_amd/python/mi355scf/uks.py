@@ -83,6 +83,7 @@ class UKS(UHF):
 
     def _fock_pair(self, dm):
         """One collective per Fock build: [J(2) | K(2) | Vxc(2) | N_alpha N_beta E_xc] partial sums in one flat buffer."""
+        self.n_fock_builds = getattr(self, "n_fock_builds", 0) + 1
         eng = self.engine
         n = eng.nao
         nn = n * n

@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _worker(rank, world, port, method, q):
+    try:
+        _worker_body(rank, world, port, method, q)
+    except BaseException as e:   # never leave the parent waiting on the queue
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def _worker_body(rank, world, port, method, q):
     sys.path.insert(0, os.path.join(ROOT, "computational-chemistry-ai_amd", "python"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -34,7 +43,7 @@ def _worker(rank, world, port, method, q):
     mf.shard(rank, world)
     parallel.reset_stats()
     e = mf.kernel()
-    coll = dict(parallel.STATS, fock_builds=mf.cycles + 2)     # initial build + one per cycle + the extra cycle
+    coll = dict(parallel.STATS, fock_builds=mf.n_fock_builds)   # initial build + one per cycle (+ redone ones) + the extra cycle
     st = mf.engine.stats()
     g = mf.nuc_grad_method().kernel()
     q.put((rank, e, bool(mf.converged), st["n_tiles"], st["n_unique_eri"], g.tolist(), coll, float(e).hex()))
@@ -65,9 +74,12 @@ def test_two_rank_sharded_scf_matches_single(method):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, method, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in procs)
+    res = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert not any(r[1] == "error" for r in res), [r[2] for r in res if r[1] == "error"]
     assert all(r[2] for r in res)
     assert abs(res[0][1] - e1) < 5e-9 and abs(res[1][1] - e1) < 5e-9
     assert res[0][3] + res[1][3] == st1["n_tiles"] and min(res[0][3], res[1][3]) > 0
@@ -76,10 +88,10 @@ def test_two_rank_sharded_scf_matches_single(method):
     for r in res:   # sharded analytic gradient (tasks + grid split over ranks, all-reduced) == unsharded
         assert np.abs(np.array(r[5]) - g1).max() < 1e-7
     # SURVEY.md section 8e / VERDICT r1 item 6: exactly ONE collective per Fock build ([J|K] or the fused [J|K|Vxc|N|Exc]
-    # buffer) and NO broadcast inside the SCF loop -- the replicated algebra is deterministic, so the ranks' energies are
-    # bit-identical without exchanging control scalars
+    # buffer) and NO broadcast inside the SCF loop (two one-off broadcasts at set-up make the inputs identical) -- the
+    # replicated algebra is deterministic, so the ranks' energies are bit-identical without exchanging control scalars
     for r in res:
-        assert r[6]["broadcast"] == 0, r[6]
+        assert r[6]["broadcast"] == 2, r[6]       # set-up only: [S|h] and the starting density, whatever the number of cycles
         assert r[6]["all_reduce"] == r[6]["fock_builds"], r[6]
     assert res[0][7] == res[1][7], (res[0][7], res[1][7])
 
