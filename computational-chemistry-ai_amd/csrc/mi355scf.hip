@@ -3469,45 +3469,66 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
 //   (no atomics: bit-identical on every rank of a sharded run).
 // =================================================================================================
 #define SP2_TRS 32 /* trace slots per step = max diagonal workgroups (N <= 512) */
-__global__ __launch_bounds__(256) void sp2_fused_kernel(const double *Xp, const double *X2p, const double *trp, int first,
-                                                        int n, int kpad, double target, double *Xc, double *X2c, double *trc)
+// MAXM = 16-column groups a thread loads per panel row in one batch: all 4 x MAXM loads of a thread are in flight together
+// (one memory round trip for kpad <= 16 MAXM; larger matrices take two batches).  Thread t owns row t/16 and columns
+// t%16 + 16 m of both panels: no integer division, 128-byte segments per row and instruction.
+// PLAN = true: the step is a quadratic fixed by the host, Xc = ca X2p + cb Xp + cc I (no dependence on the previous
+// launch's traces; `first`: Xc = cb Xp + cc I, the affine map of the Fock matrix); PLAN = false: trace-correcting SP2.
+struct Sp2Coef { double a, b, c; };
+template <int MAXM, bool PLAN>
+__global__ __launch_bounds__(256) void sp2_fused_kernel(const double *__restrict__ Xp, const double *__restrict__ X2p,
+                                                        const double *__restrict__ trp, int first, int n, int kpad, double target,
+                                                        double *__restrict__ Xc, double *__restrict__ X2c, double *__restrict__ trc,
+                                                        Sp2Coef cf)
 {
     extern __shared__ double lds[];
     double *Pa = lds;                       // [16][kpad+4]  rows i0..i0+15 of Xc
     double *Pb = lds + 16 * (kpad + 4);     // [16][kpad+4]  rows j0..j0+15 of Xc
-    double *red = Pb + 16 * (kpad + 4);     // [4][256]
+    double *red = Pb + 16 * (kpad + 4);     // [4][256]  (its first 64 doubles also stage the partial traces)
     const int ldp = kpad + 4;               // +4 doubles: breaks the power-of-two LDS row stride
     const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
-    // the branch decision needs the traces of the previous launch (memory-side atomics: a full-latency
-    // read).  Issue it together with the panel loads and select afterwards, so the two latencies overlap.
-    double tx = 0.0, tx2 = 0.0;
-    if (!first) {
-        const int nbd = (n + 15) / 16;
-        for (int b = 0; b < nbd; b++) { tx += trp[2 * b]; tx2 += trp[2 * b + 1]; }
-    }
-    constexpr int PER = 16; // panel elements per thread per batch
-    for (int base = 0; base < 16 * kpad; base += 256 * PER) {
-        double xa[PER], ya[PER], xb[PER], yb[PER];
+    const int t = threadIdx.x, r = t >> 4, c = t & 15;
+    const int nbd = (n + 15) / 16;
+    // partial traces of the previous launch: ONE coalesced load (thread b <- slot b), staged in LDS and added in index order
+    // by everybody -- issued together with the panel loads so that the latencies overlap
+    double trv = 0.0;
+    if (!PLAN && !first && t < 2 * nbd) trv = trp[t];
+    const bool ra = i0 + r < n, rb = j0 + r < n;
+    const double *xa_row = Xp + (size_t)(i0 + r) * n, *xb_row = Xp + (size_t)(j0 + r) * n;
+    const double *ya_row = X2p + (size_t)(i0 + r) * n, *yb_row = X2p + (size_t)(j0 + r) * n;
+    const int mtot = kpad >> 4;
+    bool sq = false;
+    for (int m0 = 0; m0 < mtot; m0 += MAXM) {
+        double xa[MAXM], ya[MAXM], xb[MAXM], yb[MAXM];
 #pragma unroll
-        for (int u = 0; u < PER; u++) {
-            int idx = base + u * 256 + threadIdx.x;
-            int r = idx / kpad, k = idx - r * kpad;
-            bool in = idx < 16 * kpad && k < n;
-            bool ina = in && (i0 + r < n), inb = in && (j0 + r < n);
-            size_t oa = (size_t)(i0 + r) * n + k, ob = (size_t)(j0 + r) * n + k;
-            xa[u] = ina ? Xp[oa] : 0.0;
-            xb[u] = inb ? Xp[ob] : 0.0;
-            ya[u] = (ina && !first) ? X2p[oa] : 0.0;
-            yb[u] = (inb && !first) ? X2p[ob] : 0.0;
+        for (int u = 0; u < MAXM; u++) {
+            const int k = c + 16 * (m0 + u);
+            const bool in = (m0 + u < mtot) && k < n;
+            xa[u] = (in && ra) ? xa_row[k] : 0.0;
+            xb[u] = (in && rb) ? xb_row[k] : 0.0;
+            ya[u] = (in && ra && !first) ? ya_row[k] : 0.0;
+            yb[u] = (in && rb && !first) ? yb_row[k] : 0.0;
         }
-        const bool sq = !first && fabs(tx2 - target) < fabs(2.0 * tx - tx2 - target);
+        if (!PLAN && m0 == 0 && !first) {
+            red[t] = trv;
+            __syncthreads();
+            double tx = 0.0, tx2 = 0.0;
+            for (int b = 0; b < nbd; b++) { tx += red[2 * b]; tx2 += red[2 * b + 1]; }
+            sq = fabs(tx2 - target) < fabs(2.0 * tx - tx2 - target);
+            __syncthreads();                 // `red` is reused by the K-split reduction below
+        }
 #pragma unroll
-        for (int u = 0; u < PER; u++) {
-            int idx = base + u * 256 + threadIdx.x;
-            if (idx < 16 * kpad) {
-                int r = idx / kpad, k = idx - r * kpad;
-                Pa[r * ldp + k] = first ? xa[u] : (sq ? ya[u] : 2.0 * xa[u] - ya[u]);
-                Pb[r * ldp + k] = first ? xb[u] : (sq ? yb[u] : 2.0 * xb[u] - yb[u]);
+        for (int u = 0; u < MAXM; u++) {
+            const int k = c + 16 * (m0 + u);
+            if (m0 + u < mtot) {
+                if (PLAN) {   // zero padding (k >= n, rows >= n) must stay zero: the identity term only on real diagonal elements
+                    const double da = (ra && k < n && k == i0 + r) ? cf.c : 0.0, db = (rb && k < n && k == j0 + r) ? cf.c : 0.0;
+                    Pa[r * ldp + k] = fma(cf.a, ya[u], fma(cf.b, xa[u], da));
+                    Pb[r * ldp + k] = fma(cf.a, yb[u], fma(cf.b, xb[u], db));
+                } else {
+                    Pa[r * ldp + k] = first ? xa[u] : (sq ? ya[u] : 2.0 * xa[u] - ya[u]);
+                    Pb[r * ldp + k] = first ? xb[u] : (sq ? yb[u] : 2.0 * xb[u] - yb[u]);
+                }
             }
         }
     }
@@ -3519,14 +3540,14 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *Xp, const 
     const double *pb = Pb + (lane & 15) * ldp + wave * kq + (lane >> 4);
     for (int k = 0; k < kq; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k], pb[k], acc, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
+    for (int q = 0; q < 4; q++) red[wave * 256 + q * 64 + lane] = acc[q];
     __syncthreads();
     if (wave == 0) {
         double tr2 = 0.0, tr1 = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            double v = red[r * 64 + lane] + red[256 + r * 64 + lane] + red[512 + r * 64 + lane] + red[768 + r * 64 + lane];
-            int col = lane & 15, row = (lane >> 4) + 4 * r; // f64 MFMA C/D layout
+        for (int q = 0; q < 4; q++) {
+            double v = (red[q * 64 + lane] + red[256 + q * 64 + lane]) + (red[512 + q * 64 + lane] + red[768 + q * 64 + lane]);
+            int col = lane & 15, row = (lane >> 4) + 4 * q; // f64 MFMA C/D layout
             int gi = i0 + row, gj = j0 + col;
             if (gi < n && gj < n) {
                 X2c[(size_t)gi * n + gj] = v;
@@ -3541,6 +3562,18 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *Xp, const 
         }
     }
 }
+
+typedef void (*sp2_fused_fn)(const double *, const double *, const double *, int, int, int, double, double *, double *, double *, Sp2Coef);
+template <bool PLAN> static sp2_fused_fn sp2_fused_for_t(int kpad)
+{
+    const int m = kpad >> 4;
+    if (m <= 8) return sp2_fused_kernel<8, PLAN>;
+    if (m <= 12) return sp2_fused_kernel<12, PLAN>;
+    if (m <= 16) return sp2_fused_kernel<16, PLAN>;
+    if (m <= 20) return sp2_fused_kernel<20, PLAN>;
+    return sp2_fused_kernel<16, PLAN>; // two batches
+}
+static sp2_fused_fn sp2_fused_for(int kpad) { return sp2_fused_for_t<false>(kpad); }
 
 // d_X (in/out), d_X2 (in if have_x2, out), d_work: 2*n*n doubles, d_tr: (nit+2)*2*SP2_TRS doubles (device).
 // On return d_X = X_nit, d_X2 = X_nit^2 and d_tr_out points at the 2*ceil(n/16) partial traces {tr X, tr X^2} interleaved
@@ -3559,13 +3592,14 @@ extern "C" int mi_sp2_iterate(mi_ctx *c, double *d_X, double *d_X2, int nit, dou
     const size_t nn = (size_t)n * n;
     (void)have_x2; // X^2 and the traces of the incoming X are always (re)derived by the first pass
     constexpr int TS = 2 * SP2_TRS;
+    const sp2_fused_fn sp2_fused_kernel = sp2_fused_for(kpad);
     double *cur_x = d_X, *cur_x2 = d_X2, *nxt_x = d_work, *nxt_x2 = d_work + nn;
     int slot = 0;
-    hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur_x, cur_x2, d_tr, 1, n, kpad, n_occ, nxt_x, nxt_x2, d_tr + TS * slot);
+    hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur_x, cur_x2, d_tr, 1, n, kpad, n_occ, nxt_x, nxt_x2, d_tr + TS * slot, Sp2Coef{});
     std::swap(cur_x, nxt_x); std::swap(cur_x2, nxt_x2);
     for (int it = 0; it < nit; it++) {
         hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur_x, cur_x2, d_tr + TS * slot, 0, n, kpad, n_occ, nxt_x, nxt_x2,
-                           d_tr + TS * (slot + 1));
+                           d_tr + TS * (slot + 1), Sp2Coef{});
         slot++;
         std::swap(cur_x, nxt_x); std::swap(cur_x2, nxt_x2);
     }
@@ -3593,12 +3627,46 @@ extern "C" int mi_sp2_iterate_pingpong(mi_ctx *c, double *d_A, double *d_B, int 
     dim3 grid(nb, nb), block(256);
     const size_t nn = (size_t)n * n;
     constexpr int TS = 2 * SP2_TRS;
+    const sp2_fused_fn sp2_fused_kernel = sp2_fused_for(kpad);
     double *cur = d_A, *nxt = d_B;
-    hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur, cur + nn, d_tr, 1, n, kpad, n_occ, nxt, nxt + nn, d_tr);
+    hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur, cur + nn, d_tr, 1, n, kpad, n_occ, nxt, nxt + nn, d_tr, Sp2Coef{});
     std::swap(cur, nxt);
     for (int it = 0; it < nit; it++) {
         hipLaunchKernelGGL(sp2_fused_kernel, grid, block, shm, st, cur, cur + nn, d_tr + TS * it, 0, n, kpad, n_occ, nxt, nxt + nn,
-                           d_tr + TS * (it + 1));
+                           d_tr + TS * (it + 1), Sp2Coef{});
+        std::swap(cur, nxt);
+    }
+    HIPCHK(hipGetLastError());
+    *d_tr_out = d_tr + TS * nit;
+    *d_res = cur;
+    return 0;
+}
+
+// Planned purification (round 2): the host knows inner bounds of the HOMO / LUMO and outer bounds of the spectrum (from the
+// last diagonalisation) and fixes the whole sequence of quadratics in advance -- each step folds one band of the spectrum
+// about a point inside it, (x - c)^2 or -(x - c)^2, and rescales to [0, 1]: about half the steps of trace-correcting SP2.
+// Pass 0 maps the Fock matrix, X_0 = coef[1] F + coef[2] I; pass k = 1..nit applies X_k = a X_{k-1}^2 + b X_{k-1} + c I
+// (coef[3k..3k+2]); every pass also leaves X_k^2 and the partial traces (validation by the caller: tr(X - X^2), tr X).
+// d_F is only read; d_A, d_B: two [X | X2] buffers of 2 n^2 doubles; *d_res = the one holding {X_nit, X_nit^2}.
+extern "C" int mi_sp2_iterate_planned(mi_ctx *c, const double *d_F, double *d_A, double *d_B, int nit, const double *coef, double *d_tr,
+                                      double **d_tr_out, double **d_res, void *stream)
+{
+    if (!c || !d_F || !d_A || !d_B || !coef || !d_tr || !d_tr_out || !d_res || nit < 0) return fail("mi_sp2_iterate_planned: bad argument");
+    const int n = c->nao;
+    if (n > 512) return fail("mi_sp2_iterate_planned: fused path is for N <= 512");
+    hipStream_t st = (hipStream_t)stream;
+    const int kpad = ((n + 15) / 16) * 16;
+    const size_t shm = sizeof(double) * (2 * 16 * (kpad + 4) + 4 * 256);
+    const int nb = (n + 15) / 16;
+    dim3 grid(nb, nb), block(256);
+    const size_t nn = (size_t)n * n;
+    constexpr int TS = 2 * SP2_TRS;
+    const sp2_fused_fn kern = sp2_fused_for_t<true>(kpad);
+    double *cur = d_A, *nxt = d_B;
+    hipLaunchKernelGGL(kern, grid, block, shm, st, d_F, d_F, d_tr, 1, n, kpad, 0.0, cur, cur + nn, d_tr, Sp2Coef{0.0, coef[1], coef[2]});
+    for (int it = 1; it <= nit; it++) {
+        hipLaunchKernelGGL(kern, grid, block, shm, st, cur, cur + nn, d_tr, 0, n, kpad, 0.0, nxt, nxt + nn, d_tr + TS * it,
+                           Sp2Coef{coef[3 * it], coef[3 * it + 1], coef[3 * it + 2]});
         std::swap(cur, nxt);
     }
     HIPCHK(hipGetLastError());

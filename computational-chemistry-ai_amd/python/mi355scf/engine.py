@@ -86,6 +86,7 @@ def lib():
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_sp2_iterate.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, ctypes.POINTER(vp), vp]
         L.mi_sp2_iterate_pingpong.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
+        L.mi_sp2_iterate_planned.argtypes = [vp, vp, vp, vp, ctypes.c_int, dp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
         L.mi_grad_1e.argtypes = [vp, vp, vp, vp, vp]
         L.mi_grad_eri.argtypes = [vp, vp, ctypes.c_double, vp, vp]
         L.mi_grad_eri_spin.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
@@ -374,6 +375,16 @@ class Engine:
     def reduce_blocks(self):
         """Number of fixed-order partial sums `fock_energy` / `commutator_norm` write (ceil(nao^2 / 256))."""
         return (self.nao * self.nao + 255) // 256
+
+    def sp2_iterate_planned(self, F, A, B, coef, tr):
+        """Planned purification (`sp2plan.plan` coefficients [nit+1, 3]) of the orthonormal-basis Fock matrix F on two
+        [X|X2] buffers: returns (result buffer, offset in `tr` of the last pass's partial traces)."""
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        nit = coef.shape[0] - 1
+        out, res = ctypes.c_void_p(), ctypes.c_void_p()
+        _check(lib().mi_sp2_iterate_planned(self._h, F.data_ptr(), A.data_ptr(), B.data_ptr(), nit, _dp(coef), tr.data_ptr(),
+                                            ctypes.byref(out), ctypes.byref(res), self._stream()))
+        return (A if res.value == A.data_ptr() else B), (out.value - tr.data_ptr()) // 8
 
     def fock_energy(self, h, J, K, Vxc, D, kscale, F, part):
         """F = h + J - kscale K (+ Vxc); part[reduce_blocks] = partial sums of E_elec (add them in index order)."""

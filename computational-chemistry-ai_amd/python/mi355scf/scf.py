@@ -136,10 +136,18 @@ class SCF:
     #  'eigh' hipSOLVER generalised eigenproblem every cycle (what PySCF's `eig` does [MEM]).
     eig_method = "sp2"
     sp2_tol = 1e-11
+    sp2_margin = 2     # purification steps kept beyond the first one that met sp2_tol in the previous cycle
     sp2_fused = True   # small N: one fused HIP launch per SP2 step instead of rocBLAS DGEMM + update kernel
     _sp2_iters = 24
     _sp2_validated = False   # True once an iteration count has passed the checked path for this Fock spectrum
-    sp2_fused_max = 272  # measured (ping-pong kernel, no copies): fused wins at N=114 and N=264 (1.73 -> 1.60 ms/cycle), rocBLAS at N=300
+    sp2_fused_max = 320  # one fused launch per purification step up to here (single-batch panel loads), rocBLAS DGEMM + update above
+    # Planned purification (sp2plan.py): the sequence of quadratics is fixed from bounds of the spectrum and of the HOMO/LUMO
+    # taken at the last diagonalisation -- about half the steps of trace-correcting SP2.  The result is validated every cycle;
+    # when the spectrum has moved outside the margins the cycle is redone by `eigh`, which also refreshes the bounds.
+    sp2_planned = True
+    sp2_inner_margin = 0.15   # Hartree the HOMO / LUMO may move towards the gap before the plan fails
+    sp2_outer_margin = 2.0    # Hartree the extreme eigenvalues may move outwards
+    _sp2_plan = None
     _spin_restricted = True
     sync_control = False   # sharded runs: broadcast rank 0's control scalars every cycle (not needed: deterministic reductions)
     level_shift = 0.0    # Hartree; virtual-orbital shift applied to the Fock matrix that is diagonalised / purified
@@ -417,7 +425,10 @@ class SCF:
                                  torch.empty(2, n, n, dtype=torch.float64, device=fo.device))
             eng.sp2_init(fo.contiguous(), pp[0][0], ws["b"])
             res, off = eng.sp2_iterate_pingpong(pp[0], pp[1], nit, float(nocc), ws["tr"])
-            return 2.0 * res[0], ws["tr"][off:off + 2 * ((n + 15) // 16)]   # interleaved partial traces
+            # the partial traces of EVERY step (64 slots per step, 2 ceil(n/16) used): the host validates the last step and
+            # reads off the first step at which the projector was already converged (-> iteration count of the next cycle)
+            self._sp2_hist_shape = (nit + 1, (n + 15) // 16)
+            return 2.0 * res[0], ws["tr"][:off + 64]
         eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
         # larger N: rocBLAS DGEMM + fused update kernel per step, still without a host sync
         buf = getattr(self, "_sp2_buf", None)
@@ -431,6 +442,35 @@ class SCF:
             cur = 1 - cur
         torch.matmul(X, X, out=X2)
         return 2.0 * X, torch.stack([torch.trace(X), torch.trace(X2)])
+
+    def _sp2_planned_async(self, fo, nocc):
+        """Planned purification, no host sync: (D', partial traces of every pass) -- validated by the caller like the
+        optimistic SP2 path."""
+        eng = self.engine
+        n = fo.shape[0]
+        ws = getattr(self, "_sp2f", None)
+        if ws is None or ws["X"].shape[0] != n:
+            mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
+            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(64 * 80), b=mk(2 * n))
+        pp = ws.get("pp")
+        if pp is None:
+            pp = ws["pp"] = (torch.empty(2, n, n, dtype=torch.float64, device=fo.device),
+                             torch.empty(2, n, n, dtype=torch.float64, device=fo.device))
+        coef = self._sp2_plan[:self._sp2_plan_len + 1]
+        res, off = eng.sp2_iterate_planned(fo.contiguous(), pp[0], pp[1], coef, ws["tr"])
+        self._sp2_hist_shape = (coef.shape[0], (n + 15) // 16)
+        return 2.0 * res[0], ws["tr"][:off + 64]
+
+    def _sp2_replan(self, mo_e, nocc):
+        """New plan from the eigenvalues of the (orthonormal-basis) Fock matrix just diagonalised."""
+        from . import sp2plan
+        e = mo_e.cpu().numpy() if torch.is_tensor(mo_e) else np.asarray(mo_e)
+        self._sp2_plan = None
+        if self.sp2_planned and self.eig_method == "sp2" and 0 < nocc < len(e) and len(e) <= self.sp2_fused_max and self.sp2_fused:
+            b = sp2plan.bounds_from_spectrum(e, nocc, self.sp2_inner_margin, self.sp2_outer_margin)
+            self._sp2_plan = sp2plan.plan(*b)
+            if self._sp2_plan is not None:
+                self._sp2_plan_len = self._sp2_plan.shape[0] - 1
 
     def make_rdm1(self, mo_coeff=None, mo_occ=None):
         if mo_coeff is None:
@@ -539,9 +579,24 @@ class SCF:
             e_el += float(vals[pos])
             pos += 1
         if sp2_tr is not None:
-            trx, trx2 = self._sp2_traces(vals[pos:])
-            if not (abs(trx - trx2) < self.sp2_tol and abs(trx - nocc) < 1e-8):
-                return False
+            hist = vals[pos:]
+            shape = getattr(self, "_sp2_hist_shape", None)
+            if shape is not None and hist.size == shape[0] * 64:
+                h = hist.reshape(shape[0], 32, 2)[:, :shape[1], :]
+                tx, tx2 = h[:, :, 0].sum(axis=1), h[:, :, 1].sum(axis=1)     # per step, partials added in index order
+                ok = (np.abs(tx - tx2) < self.sp2_tol) & (np.abs(tx - nocc) < 1e-8)
+                if not ok[-1]:
+                    return False
+                first_ok = int(np.argmax(ok))            # steps beyond it were not needed for this Fock matrix
+                if getattr(self, "_sp2_planned_pass", False):
+                    self._sp2_plan_len = min(self._sp2_plan.shape[0] - 1, max(first_ok + 1, 4))
+                else:
+                    self._sp2_iters = max(first_ok + self.sp2_margin, 4)
+            else:
+                trx, trx2 = self._sp2_traces(hist)
+                if not (abs(trx - trx2) < self.sp2_tol and abs(trx - nocc) < 1e-8):
+                    return False
+            self._sp2_hist_shape = None
         e_tot = e_el + st["enuc"]
         # |g| = |2 F_vo| = |[F',D']|_F / sqrt(2), normalised by sqrt(n_vo) like PySCF's get_grad norm [MEM]
         gnorm = float(np.sqrt(max(c2, 0.0))) / np.sqrt(2.0) / np.sqrt(nvo)
@@ -563,15 +618,27 @@ class SCF:
             fo = fo + self.level_shift * (torch.eye(fo.shape[0], dtype=fo.dtype, device=fo.device) - 0.5 * st["dmo"])
         tr_dev = None
         use_sp2 = self.eig_method == "sp2" and not want_mo
-        if use_sp2 and self._sp2_validated and 0 < nocc < fo.shape[0] and not st.get("_redo"):
+        n = fo.shape[0]
+        planned_ok = (use_sp2 and self.sp2_planned and self.sp2_fused and n <= self.sp2_fused_max and 0 < nocc < n
+                      and not self.level_shift)
+        self._sp2_planned_pass = False
+        dmo = None
+        if planned_ok and self._sp2_plan is not None and not st.get("_redo"):
+            dmo, tr_dev = self._sp2_planned_async(fo, nocc)
+            self._sp2_planned_pass = True
+        elif planned_ok:
+            pass                                     # no plan yet: diagonalise below, which also yields the bounds for one
+        elif use_sp2 and self._sp2_validated and 0 < nocc < n and not st.get("_redo"):
             dmo, tr_dev = self._sp2_fused_async(fo, nocc)
-        else:
-            dmo = self._density_sp2(fo, nocc, orth=True) if use_sp2 else None
+        elif use_sp2:
+            dmo = self._density_sp2(fo, nocc, orth=True)
         if dmo is None:
             e, c = torch.linalg.eigh(fo)
             co = c[:, :nocc]
             dmo = 2.0 * co @ co.T
             st.update(mo_e=e, mo_c=Li.T @ c)
+            if planned_ok:
+                self._sp2_replan(e, nocc)
         else:
             st.pop("mo_e", None)
         saved = (st["dmo"], st["diis"].count) if tr_dev is not None else None
@@ -580,17 +647,20 @@ class SCF:
         e_prev = st["e_tot"]
         ok = self._after_density(st, dm, e_last=e_prev, next_cycle=st["cycle"] + 1, sp2_tr=tr_dev, nocc=nocc)
         if not ok:
-            # the optimistic purification had not converged: roll the DIIS push back and redo this cycle checked
+            # the optimistic purification had not converged (planned path: the spectrum left the planned bounds): roll the DIIS
+            # push back and redo this cycle -- planned path by diagonalisation (fresh bounds), otherwise by the checked SP2
             st["dmo"], st["diis"].count = saved
             st["e_tot"] = e_prev
             self._sp2_validated = False
             st["_redo"] = True
             try:
-                dmo = self._density_sp2(fo, nocc, orth=True)
+                dmo = None if self._sp2_planned_pass else self._density_sp2(fo, nocc, orth=True)
                 if dmo is None:
                     e, c = torch.linalg.eigh(fo)
                     co = c[:, :nocc]
                     dmo = 2.0 * co @ co.T
+                    if self._sp2_planned_pass:
+                        self._sp2_replan(e, nocc)
                 st["dmo"] = dmo
                 self._after_density(st, Li.T @ dmo @ Li, e_last=e_prev, next_cycle=st["cycle"] + 1)
             finally:

@@ -153,6 +153,13 @@ int mi_sp2_iterate(mi_ctx *ctx, double *d_X, double *d_X2, int nit, double n_occ
 int mi_sp2_iterate_pingpong(mi_ctx *ctx, double *d_A, double *d_B, int nit, double n_occ, double *d_tr, double **d_tr_out,
                             double **d_res, void *stream);
 
+/* Planned purification: the whole sequence of quadratics is fixed by the caller from bounds of the spectrum (outer) and of
+ * the HOMO / LUMO (inner) -- see mi355scf/sp2plan.py.  coef[3*(nit+1)]: pass 0 forms X_0 = coef[1] F + coef[2] I from the
+ * (orthonormal-basis) Fock matrix d_F, pass k applies X_k = coef[3k] X^2 + coef[3k+1] X + coef[3k+2] I.  Buffers and trace
+ * output as in mi_sp2_iterate_pingpong (the caller validates tr(X - X^2) and tr X of the last pass). */
+int mi_sp2_iterate_planned(mi_ctx *ctx, const double *d_F, double *d_A, double *d_B, int nit, const double *coef, double *d_tr,
+                           double **d_tr_out, double **d_res, void *stream);
+
 /* Fused elementwise pieces of one SCF cycle (rows a11/a12: get_fock + energy_elec, orbital-gradient norm):
  * mi_fock_energy: F = h + J - kscale*K (+Vxc); d_part[b] = block b's share of sum D*(h + (J - kscale*K)/2).  d_K, d_Vxc may be NULL.
  * mi_commutator_norm: E = M - M^T; d_part[b] = block b's share of |E|_F^2.
