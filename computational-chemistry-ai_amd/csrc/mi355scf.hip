@@ -244,6 +244,7 @@ struct mi_ctx {
     RunRec *d_segs = nullptr;            // runs cut at wave boundaries
     int *d_wave_seg = nullptr;           // [nwaves+1] segment range of each wave
     int n_jk_waves = 0;
+    int n_jk_cached = 0;                 // leading J/K work items kept in the Infinity Cache (default-policy loads)
     double *d_tiles = nullptr;
     int64_t tile_doubles = 0, tile_alloc = 0;
     // J/K work buffers
@@ -258,6 +259,7 @@ struct mi_ctx {
     int opt_jk_waves = 0;    // 0: one wave per work item, longest first; >0: that many waves, equal-cost shares
     int opt_jk_nt = 1;       // nontemporal loads for the tile stream
     double opt_grad_dtol = 1e-13; // gradient: skip quartets with q_ab q_cd max|G| below this (0: Schwarz only)
+    int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
 };
 
@@ -417,6 +419,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_waves") c->opt_jk_waves = (int)value; // takes effect at the next mi_eri_prepare
     else if (k == "jk_nt") c->opt_jk_nt = (int)value;
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
+    else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;   // takes effect at the next mi_eri_prepare
     else if (k == "grad_dtol") c->opt_grad_dtol = value;
     else return fail("mi_set_option: unknown key '%s'", key);
     return 0;
@@ -1411,6 +1414,15 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             std::vector<RunRec> sorted(segs.size());
             for (size_t q = 0; q < segs.size(); q++) sorted[q] = segs[ord[q]];
             segs.swap(sorted);
+            c->n_jk_cached = 0;
+            if (off * 8 > ((int64_t)256 << 20) && c->opt_jk_cache_mb > 0) {
+                double acc_b = 0.0;
+                const double lim = (double)c->opt_jk_cache_mb * 1048576.0;
+                std::vector<double> sc(segs.size(), 0.0);
+                for (size_t q = 0; q < segs.size(); q++)
+                    for (int t = 0; t < segs[q].count; t++) sc[q] += tile_cost(segs[q].first + t) - 8192.0;
+                while (c->n_jk_cached < (int)segs.size() && acc_b + sc[c->n_jk_cached] <= lim) acc_b += sc[c->n_jk_cached++];
+            }
             nw = (int)segs.size();
             wave_seg.resize(nw + 1);
             std::iota(wave_seg.begin(), wave_seg.end(), 0);
@@ -1615,6 +1627,7 @@ struct JkArgs {
     const double *D; // padded [ldp][ldp]
     double *Jacc, *Kacc;
     int ld, nao;
+    int n_cached;            // leading work items read with the default cache policy (kept in the Infinity Cache)
 };
 
 __device__ inline double red_select_xor(double a, double b, bool hi, int mask)
@@ -1638,16 +1651,14 @@ __device__ inline double reduce8(const double v[8], int lane, int m2, int m1, in
 }
 
 template <bool WITH_J, bool WITH_K, bool NT>
-__global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
+__device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
 {
     const int lane = threadIdx.x;
     const int i = lane >> 3, k = lane & 7;
-    const MI_CONST_AS int *wave_seg = as_const(A.wave_seg);
     const MI_CONST_AS int *tile_I = as_const(A.tile_I);
     const MI_CONST_AS int64_t *tile_off = as_const(A.tile_off);
     const MI_CONST_AS double *Du = as_const(A.D);
-    const int seg_end = wave_seg[blockIdx.x + 1];
-  for (int seg = wave_seg[blockIdx.x]; seg < seg_end; seg++) {
+  {
     const MI_CONST_AS RunRec *rr = as_const(A.runs) + seg;
     const RunRec R{rr->J, rr->K, rr->L, rr->first, rr->count};
     const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
@@ -1748,7 +1759,21 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
         double r2 = reduce8(s, lane, 4, 2, 1); // lane holds l = k, summed over k-lanes
         atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + L0 + k], r2);
     }
-  } // segments of this wave
+  }
+}
+
+// The first `n_cached` work items (the longest segments) are read with the default cache policy, everything else with
+// nontemporal loads: on a tensor larger than the 256 MiB Infinity Cache the nontemporal stream does not evict them, so that
+// share of the tiles is served on-die in every SCF cycle after the first instead of from HBM.
+template <bool WITH_J, bool WITH_K, bool NT>
+__global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
+{
+    const MI_CONST_AS int *wave_seg = as_const(A.wave_seg);
+    const int seg_end = wave_seg[blockIdx.x + 1];
+    for (int seg = wave_seg[blockIdx.x]; seg < seg_end; seg++) {
+        if (NT && seg < A.n_cached) jk_segment<WITH_J, WITH_K, false>(A, seg);
+        else jk_segment<WITH_J, WITH_K, NT>(A, seg);
+    }
 }
 
 
@@ -1990,7 +2015,8 @@ __global__ void finalize_jk_kernel(const double *Jacc, const double *Kacc, doubl
 
 static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
 {
-    JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao};
+    JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao,
+             c->n_jk_cached};
     if (c->n_tiles == 0) return 0;
     dim3 g(A.nruns), b(64);
     // nontemporal loads only when the tensor cannot stay in the 256 MiB Infinity Cache between SCF cycles
