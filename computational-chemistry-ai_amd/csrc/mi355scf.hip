@@ -218,6 +218,7 @@ struct mi_ctx {
     double *d_env = nullptr;
     int32_t *d_bas = nullptr, *d_atm = nullptr;
     int *d_shell_ao = nullptr;
+    double *d_shell_xyz = nullptr;       // [nbas][3]
     double *d_c2s = nullptr;             // concatenated c2s tables l=0..LMAX
     int c2s_off[LMAX + 2];
     RysDev rys;                          // device pointers inside
@@ -259,6 +260,7 @@ struct mi_ctx {
     int opt_jk_waves = 0;    // 0: one wave per work item, longest first; >0: that many waves, equal-cost shares
     int opt_jk_nt = 1;       // nontemporal loads for the tile stream
     double opt_grad_dtol = 1e-13; // gradient: skip quartets with q_ab q_cd max|G| below this (0: Schwarz only)
+    int opt_eri_tpq = 1;     // thread-per-quartet fused ERI kernels for the low angular classes (0: wave-per-quartet pair everywhere)
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
 };
@@ -312,6 +314,13 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
     HIPCHK(hipMemcpy(c->d_atm, atm, sizeof(int32_t) * natm * ATM_SLOTS, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->d_shell_ao, sizeof(int) * (nbas + 1)));
     HIPCHK(hipMemcpy(c->d_shell_ao, shell_ao.data(), sizeof(int) * (nbas + 1), hipMemcpyHostToDevice));
+    {
+        std::vector<double> xyz((size_t)nbas * 3);
+        for (int i = 0; i < nbas; i++)
+            for (int d = 0; d < 3; d++) xyz[3 * i + d] = c->shells[i].r[d];
+        HIPCHK(hipMalloc(&c->d_shell_xyz, sizeof(double) * xyz.size()));
+        HIPCHK(hipMemcpy(c->d_shell_xyz, xyz.data(), sizeof(double) * xyz.size(), hipMemcpyHostToDevice));
+    }
     // c2s tables
     std::vector<double> all;
     for (int l = 0; l <= LMAX; l++) {
@@ -404,7 +413,7 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     hipSetDevice(c->device);
     free_eri(c);
     void *ptrs[] = {c->d_env, c->d_bas, c->d_atm, c->d_shell_ao, c->d_c2s, c->d_rys_cheb, c->d_herm_r, c->d_herm_w,
-                    c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red};
+                    c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red, c->d_shell_xyz};
     for (void *p : ptrs) if (p) hipFree(p);
     delete c;
 }
@@ -419,7 +428,8 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_waves") c->opt_jk_waves = (int)value; // takes effect at the next mi_eri_prepare
     else if (k == "jk_nt") c->opt_jk_nt = (int)value;
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
-    else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;   // takes effect at the next mi_eri_prepare
+    else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
+    else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;   // takes effect at the next mi_eri_prepare
     else if (k == "grad_dtol") c->opt_grad_dtol = value;
     else return fail("mi_set_option: unknown key '%s'", key);
     return 0;
@@ -959,6 +969,285 @@ __global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
     }
 }
 
+// =================================================================================================
+// ERI generation for the LOW angular classes: one THREAD per contracted shell quartet, everything in registers, one launch.
+//
+// The wave-per-quartet pair (eri_rys_kernel + eri_transform_scatter) is latency bound on the classes that make up three
+// quarters of all quartets ((ss|ss) ... (dp|ps), (fs|ds)): a handful of components keeps 64 lanes idle and the [e0|f0] block
+// makes a round trip through memory between the two kernels.  Here the angular momenta are template parameters, so that the
+// primitive loop (Rys roots -> 2-D recurrence -> component products), the horizontal recurrence, the cartesian->spherical
+// transforms and the scatter into the resident tiles unroll completely into register code; 64 quartets per wave are in
+// flight instead of 1-4.  The Chebyshev coefficients of the Rys roots/weights for this root count (3.5-13 KB) are staged in
+// LDS once per workgroup (the per-lane table look-ups then never leave the CU).
+// Eligible: NE * NF <= 64 accumulators and <= 3 roots (17 classes up to (dp|ps), (ds|ds), (fs|ds), (fd|ss)).
+// =================================================================================================
+__host__ __device__ constexpr int c_ncart(int l) { return (l + 1) * (l + 2) / 2; }
+__host__ __device__ constexpr int c_cidx(int l, int lx, int ly) { return (l - lx) * (l - lx + 1) / 2 + (l - lx - ly); }
+__host__ __device__ constexpr int c_eoff(int la, int deg) { int n = 0; for (int e = la; e < deg; e++) n += c_ncart(e); return n; }
+__host__ __device__ constexpr int c_ne(int la, int lb) { return c_eoff(la, la + lb + 1); }
+__host__ __device__ constexpr int c_binom(int n, int k) { int r = 1; for (int i = 1; i <= k; i++) r = r * (n - k + i) / i; return r; }
+
+struct TpqArgs {
+    const PairRec *bra, *ket;
+    const double *prim;
+    const int64_t *prefix;
+    int nbra;
+    int64_t t0, ntask;
+    const double *c2s;
+    int c2s_off[LMAX + 2];
+    RysDev rys;
+    XfArgs X;       // tile directory (tile_table, tile_off, tiles, nao) for put_tile
+    const double *shell_xyz; // [nbas][3] shell centres (Bohr)
+    int check_owner;
+};
+
+// HRR + cart->sph of one shell pair applied to one index of a register array:
+//   in [NE] (E-index, degrees L1 .. L1+L2) -> out [(2L1+1)(2L2+1)];  element (idx, o) lives at idx * SI + o * SO.
+template <int L1, int L2, int NO, int SI_IN, int SO_IN, int SI_OUT, int SO_OUT>
+__device__ __forceinline__ void tpq_pair_transform(const double *in, double *out, const double AB[3], const MI_CONST_AS double *c1,
+                                                   const MI_CONST_AS double *c2)
+{
+    constexpr int NCA = c_ncart(L1), NCB = c_ncart(L2), NSA = 2 * L1 + 1, NSB = 2 * L2 + 1;
+    double pw[3][L2 + 1];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        pw[d][0] = 1.0;
+#pragma unroll
+        for (int q = 1; q <= L2; q++) pw[d][q] = pw[d][q - 1] * AB[d];
+    }
+#pragma unroll
+    for (int o = 0; o < NO; o++) {
+        // horizontal recurrence (closed form): (a b| = sum_{i <= b} C(b,i) AB^(b-i) (a+i 0|
+        double g[NCA * NCB];
+#pragma unroll
+        for (int ax = L1; ax >= 0; ax--)
+#pragma unroll
+            for (int ay = L1 - ax; ay >= 0; ay--) {
+                const int az = L1 - ax - ay, ia = c_cidx(L1, ax, ay);
+#pragma unroll
+                for (int bx = L2; bx >= 0; bx--)
+#pragma unroll
+                    for (int by = L2 - bx; by >= 0; by--) {
+                        const int bz = L2 - bx - by, ib = c_cidx(L2, bx, by);
+                        double v = 0.0;
+#pragma unroll
+                        for (int ix = 0; ix <= bx; ix++)
+#pragma unroll
+                            for (int iy = 0; iy <= by; iy++)
+#pragma unroll
+                                for (int iz = 0; iz <= bz; iz++) {
+                                    const int deg = L1 + ix + iy + iz;
+                                    const int e = c_eoff(L1, deg) + c_cidx(deg, ax + ix, ay + iy);
+                                    const double cf = (double)(c_binom(bx, ix) * c_binom(by, iy) * c_binom(bz, iz));
+                                    v = fma(cf * pw[0][bx - ix] * pw[1][by - iy] * pw[2][bz - iz], in[e * SI_IN + o * SO_IN], v);
+                                }
+                        g[ia * NCB + ib] = v;
+                    }
+            }
+        // cartesian -> spherical on both shells (coefficient tables in constant memory: scalar loads)
+        double h[NSA * NCB];
+#pragma unroll
+        for (int s1 = 0; s1 < NSA; s1++)
+#pragma unroll
+            for (int b = 0; b < NCB; b++) {
+                double v = 0.0;
+#pragma unroll
+                for (int a = 0; a < NCA; a++) v = fma(c1[a * NSA + s1], g[a * NCB + b], v);
+                h[s1 * NCB + b] = v;
+            }
+#pragma unroll
+        for (int s1 = 0; s1 < NSA; s1++)
+#pragma unroll
+            for (int s2 = 0; s2 < NSB; s2++) {
+                double v = 0.0;
+#pragma unroll
+                for (int b = 0; b < NCB; b++) v = fma(c2[b * NSB + s2], h[s1 * NCB + b], v);
+                out[(s1 * NSB + s2) * SI_OUT + o * SO_OUT] = v;
+            }
+    }
+}
+
+#define TPQ_BLOCK 128
+template <int LA, int LB, int LC, int LD>
+__global__ __launch_bounds__(TPQ_BLOCK) void eri_tpq_kernel(TpqArgs A)
+{
+    constexpr int NR = (LA + LB + LC + LD) / 2 + 1;
+    constexpr int NMAX = LA + LB, MMAX = LC + LD;
+    constexpr int NE = c_ne(LA, LB), NF = c_ne(LC, LD);
+    constexpr int NSAB = (2 * LA + 1) * (2 * LB + 1), NSCD = (2 * LC + 1) * (2 * LD + 1);
+    extern __shared__ double cheb[];   // Chebyshev coefficients of the 2 NR root/weight functions, all intervals
+    const int nint = A.rys.nint[NR];
+    {
+        const int ntab = nint * 2 * NR * (RYS_DEG + 1);
+        const double *src = A.rys.cheb + A.rys.off[NR];
+        for (int q = threadIdx.x; q < ntab; q += TPQ_BLOCK) cheb[q] = src[q];
+    }
+    __syncthreads();
+    const int64_t tl = (int64_t)blockIdx.x * TPQ_BLOCK + threadIdx.x;
+    if (tl >= A.ntask) return;
+    int ib, ik;
+    find_task(A.prefix, A.nbra, A.t0 + tl, ib, ik);
+    const PairRec ab = A.bra[ib], cd = A.ket[ik];
+    constexpr int ni = 2 * LA + 1, nj = 2 * LB + 1, nk = 2 * LC + 1, nl = 2 * LD + 1;
+    // block ranges of the four shells: which index images can land in a canonical tile, and is anything resident here
+    const int lo[4] = {ab.ao_i >> 3, ab.ao_j >> 3, cd.ao_i >> 3, cd.ao_j >> 3};
+    const int hi[4] = {(ab.ao_i + ni - 1) >> 3, (ab.ao_j + nj - 1) >> 3, (cd.ao_i + nk - 1) >> 3, (cd.ao_j + nl - 1) >> 3};
+    if (A.check_owner) {
+        bool hit = false;
+        for (int q = 0; q < 16; q++) {
+            int I = (q & 1) ? hi[0] : lo[0], J = (q & 2) ? hi[1] : lo[1], K = (q & 4) ? hi[2] : lo[2], L = (q & 8) ? hi[3] : lo[3];
+            int h1 = max(I, J), l1 = min(I, J), bij = h1 * (h1 + 1) / 2 + l1;
+            int h2 = max(K, L), l2 = min(K, L), bkl = h2 * (h2 + 1) / 2 + l2;
+            int bmax = max(bij, bkl), bmin = min(bij, bkl);
+            hit = hit || A.X.tile_table[(size_t)bmax * (bmax + 1) / 2 + bmin] >= 0;
+        }
+        if (!hit) return;
+    }
+
+    double acc[NE * NF];
+#pragma unroll
+    for (int q = 0; q < NE * NF; q++) acc[q] = 0.0;
+    for (int ip = 0; ip < ab.nprim; ip++) {
+        const double *b = A.prim + (size_t)(ab.prim_off + ip) * 8;
+        const double p = b[0], Px = b[1], Py = b[2], Pz = b[3], Kab = b[7];
+        const double PA[3] = {b[4], b[5], b[6]};
+        for (int jp = 0; jp < cd.nprim; jp++) {
+            const double *kk = A.prim + (size_t)(cd.prim_off + jp) * 8;
+            const double q = kk[0];
+            const double PQ[3] = {Px - kk[1], Py - kk[2], Pz - kk[3]};
+            const double QC[3] = {kk[4], kk[5], kk[6]};
+            const double pq1 = 1.0 / (p + q);
+            const double x = p * q * pq1 * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
+            const double pref = Kab * kk[7] * 34.986836655249725 /* 2 pi^2.5 */ * pq1 * sqrt(p + q) / (p * q);
+            // Rys roots u_r and weights w_r: Chebyshev interpolation from the LDS copy, asymptotic form beyond the table
+            double u[NR], w[NR];
+            if (x < nint * RYS_H) {
+                int iv = (int)(x * (1.0 / RYS_H));
+                if (iv >= nint) iv = nint - 1;
+                const double sx = (x - (iv * RYS_H + 0.5 * RYS_H)) * (2.0 / RYS_H), s2 = 2.0 * sx;
+                const double *cb = cheb + (size_t)iv * 2 * NR * (RYS_DEG + 1);
+#pragma unroll
+                for (int f = 0; f < 2 * NR; f++) {
+                    const double *cc = cb + f * (RYS_DEG + 1);
+                    double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+                    for (int kq = RYS_DEG; kq >= 1; kq--) {
+                        double tq = s2 * b1 - b2 + cc[kq];
+                        b2 = b1;
+                        b1 = tq;
+                    }
+                    const double val = sx * b1 - b2 + cc[0];
+                    if (f < NR) u[f] = val; else w[f - NR] = val;
+                }
+            } else {
+                const double rx = 1.0 / x, rsx = rsqrt(x);
+#pragma unroll
+                for (int f = 0; f < NR; f++) { u[f] = A.rys.herm_r[NR * RYS_NMAX + f] * rx; w[f] = A.rys.herm_w[NR * RYS_NMAX + f] * rsx; }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const double ur = u[r];
+                const double b00 = 0.5 * ur * pq1, b10 = 0.5 / p * (1.0 - ur * q * pq1), b01 = 0.5 / q * (1.0 - ur * p * pq1);
+                double T[3][NMAX + 1][MMAX + 1];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const double c00 = PA[d] - ur * q * pq1 * PQ[d], c01 = QC[d] + ur * p * pq1 * PQ[d];
+                    T[d][0][0] = d == 2 ? w[r] * pref : 1.0;
+#pragma unroll
+                    for (int n = 0; n < NMAX; n++) T[d][n + 1][0] = c00 * T[d][n][0] + (n > 0 ? n * b10 * T[d][n - 1][0] : 0.0);
+#pragma unroll
+                    for (int m = 0; m < MMAX; m++)
+#pragma unroll
+                        for (int n = 0; n <= NMAX; n++) {
+                            double v = c01 * T[d][n][m];
+                            if (m > 0) v = fma(m * b01, T[d][n][m - 1], v);
+                            if (n > 0) v = fma(n * b00, T[d][n - 1][m], v);
+                            T[d][n][m + 1] = v;
+                        }
+                }
+                // component products: e = (ex,ey,ez) of degree LA..LA+LB, f of degree LC..LC+LD (orders as build_comp_table)
+#pragma unroll
+                for (int de = LA; de <= LA + LB; de++)
+#pragma unroll
+                    for (int ex = de; ex >= 0; ex--)
+#pragma unroll
+                        for (int ey = de - ex; ey >= 0; ey--) {
+                            const int ez = de - ex - ey, ie = c_eoff(LA, de) + c_cidx(de, ex, ey);
+#pragma unroll
+                            for (int df = LC; df <= LC + LD; df++)
+#pragma unroll
+                                for (int fx = df; fx >= 0; fx--)
+#pragma unroll
+                                    for (int fy = df - fx; fy >= 0; fy--) {
+                                        const int fz = df - fx - fy, jf = c_eoff(LC, df) + c_cidx(df, fx, fy);
+                                        acc[ie * NF + jf] = fma(T[0][ex][fx] * T[1][ey][fy], T[2][ez][fz], acc[ie * NF + jf]);
+                                    }
+                        }
+            }
+        }
+    }
+    // HRR + cart->sph: bra index first ([NE][NF] -> [NSAB][NF]), then the ket index ([NSAB][NF] -> [NSAB][NSCD])
+    const MI_CONST_AS double *c2s = as_const(A.c2s);
+    // AB = A - B of each pair (first minus second shell of the record) from the shell centres
+    double ABv[3], CDv[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        ABv[d] = A.shell_xyz[3 * ab.sh_i + d] - A.shell_xyz[3 * ab.sh_j + d];
+        CDv[d] = A.shell_xyz[3 * cd.sh_i + d] - A.shell_xyz[3 * cd.sh_j + d];
+    }
+    double X1[NSAB * NF];
+    tpq_pair_transform<LA, LB, NF, NF, 1, NF, 1>(acc, X1, ABv, c2s + A.c2s_off[LA], c2s + A.c2s_off[LB]);
+    double out[NSAB * NSCD];
+    tpq_pair_transform<LC, LD, NSAB, 1, NF, 1, NSCD>(X1, out, CDv, c2s + A.c2s_off[LC], c2s + A.c2s_off[LD]);
+    // scatter every symmetry image that lands in a canonical resident tile.  The directory look-up (two dependent global
+    // loads) is done once per change of tile, not per element: the elements of an image touch at most 16 tiles, usually one.
+    auto ok = [&](int a, int b, int c, int d) { return hi[a] >= lo[b] && hi[c] >= lo[d]; };
+    const unsigned mask = (ok(0, 1, 2, 3) ? 1u : 0u) | (ok(1, 0, 2, 3) ? 2u : 0u) | (ok(0, 1, 3, 2) ? 4u : 0u) | (ok(1, 0, 3, 2) ? 8u : 0u) |
+                          (ok(2, 3, 0, 1) ? 16u : 0u) | (ok(3, 2, 0, 1) ? 32u : 0u) | (ok(2, 3, 1, 0) ? 64u : 0u) | (ok(3, 2, 1, 0) ? 128u : 0u);
+    const MI_CONST_AS int32_t *ttab = as_const(A.X.tile_table);
+    const MI_CONST_AS int64_t *toff = as_const(A.X.tile_off);
+    const int nao = A.X.nao;
+#pragma unroll
+    for (int img = 0; img < 8; img++) {
+        // images 5 and 6 of this construction are (k,l,j,i) and (l,k,i,j): bits 6 and 5 of the block-range mask
+        const int mbit = img == 5 ? 6 : (img == 6 ? 5 : img);
+        if (!(mask & (1u << mbit))) continue;
+        size_t slot_c = ~(size_t)0;
+        int64_t base_c = -1;
+#pragma unroll
+        for (int sa = 0; sa < ni; sa++)
+#pragma unroll
+            for (int sb = 0; sb < nj; sb++)
+#pragma unroll
+                for (int sc = 0; sc < nk; sc++)
+#pragma unroll
+                    for (int sd = 0; sd < nl; sd++) {
+                        const int a0 = ab.ao_i + sa, a1 = ab.ao_j + sb, a2 = cd.ao_i + sc, a3 = cd.ao_j + sd;
+                        // image `img`: bit 0 swaps the bra pair, bit 1 the ket pair, bit 2 exchanges bra and ket
+                        int i = (img & 1) ? a1 : a0, j = (img & 1) ? a0 : a1, k = (img & 2) ? a3 : a2, l = (img & 2) ? a2 : a3;
+                        if (img & 4) { int t_ = i; i = k; k = t_; t_ = j; j = l; l = t_; }
+                        const int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
+                        if (I < J || K < L) continue;
+                        const int bij = I * (I + 1) / 2 + J, bkl = K * (K + 1) / 2 + L;
+                        if (bij < bkl) continue;
+                        const size_t slot = (size_t)bij * (bij + 1) / 2 + bkl;
+                        if (slot != slot_c) {
+                            slot_c = slot;
+                            const int32_t t = ttab[slot];
+                            base_c = t >= 0 ? toff[t] : -1;
+                        }
+                        if (base_c < 0) continue;
+                        double wv = out[(sa * nj + sb) * NSCD + sc * nl + sd];
+                        if (I == J) wv *= 0.5;
+                        if (K == L) wv *= 0.5;
+                        if (bij == bkl) wv *= 0.5;
+                        const int bi = min(BLK, nao - I * BLK), bk = min(BLK, nao - K * BLK);
+                        const int ii = i & 7, jj = j & 7, kk = k & 7, ll = l & 7;
+                        A.X.tiles[base_c + ((size_t)((jj * 4 + (ll >> 1)) * (bi * bk) + ii * bk + kk) * 2 + (ll & 1))] = wv;
+                    }
+    }
+}
+
 // Schwarz: q[b] = sqrt(max_ab |(ab|ab)|) from the diagonal-task E0 blocks.
 struct SchwarzArgs {
     const PairRec *bra;
@@ -1116,6 +1405,37 @@ static void setup_eri_dims(EriArgs &E, int la, int lb, int lc, int ld)
     E.ncomp = ne_of(la, lb) * ne_of(lc, ld);
     int pb = 64 / (3 * E.nroots);
     E.PB = std::max(1, pb);
+}
+
+// Launch the thread-per-quartet kernel of an eligible class: returns 1 if launched, 0 if the class is not covered, -1 on error.
+template <int LA, int LB, int LC, int LD>
+static int launch_eri_tpq_t(const TpqArgs &Q, hipStream_t st)
+{
+    constexpr int NR = (LA + LB + LC + LD) / 2 + 1;
+    const size_t shm = sizeof(double) * (size_t)RYS_NINT_H[NR] * 2 * NR * (RYS_DEG + 1);
+    const int64_t MAXB = (int64_t)1 << 30;
+    for (int64_t t0 = 0; t0 < Q.ntask; t0 += MAXB * TPQ_BLOCK) {   // grid.x stays below 2^31
+        TpqArgs P = Q;
+        P.t0 = Q.t0 + t0;
+        P.ntask = std::min<int64_t>(Q.ntask - t0, MAXB * TPQ_BLOCK);
+        hipLaunchKernelGGL((eri_tpq_kernel<LA, LB, LC, LD>), dim3((unsigned)((P.ntask + TPQ_BLOCK - 1) / TPQ_BLOCK)), dim3(TPQ_BLOCK), shm, st, P);
+    }
+    if (hipGetLastError() != hipSuccess) return fail("eri_tpq_kernel launch failed");
+    return 1;
+}
+
+static int launch_eri_tpq(int la, int lb, int lc, int ld, const TpqArgs &Q, hipStream_t st)
+{
+    const int key = ((la * 4 + lb) * 4 + lc) * 4 + ld;
+#define TPQ_CASE(a, b, c_, d) case (((a) * 4 + (b)) * 4 + (c_)) * 4 + (d): return launch_eri_tpq_t<a, b, c_, d>(Q, st)
+    switch (key) {
+        TPQ_CASE(0, 0, 0, 0); TPQ_CASE(1, 0, 0, 0); TPQ_CASE(1, 0, 1, 0); TPQ_CASE(1, 1, 0, 0); TPQ_CASE(1, 1, 1, 0);
+        TPQ_CASE(2, 0, 0, 0); TPQ_CASE(2, 0, 1, 0); TPQ_CASE(2, 0, 1, 1); TPQ_CASE(2, 0, 2, 0); TPQ_CASE(2, 1, 0, 0);
+        TPQ_CASE(2, 1, 1, 0); TPQ_CASE(2, 2, 0, 0); TPQ_CASE(3, 0, 0, 0); TPQ_CASE(3, 0, 1, 0); TPQ_CASE(3, 0, 2, 0);
+        TPQ_CASE(3, 1, 0, 0); TPQ_CASE(3, 2, 0, 0);
+    default: return 0;
+    }
+#undef TPQ_CASE
 }
 
 // Sharding plan of the resident tile store: enumerate the (J,K,L) runs that survive the block-pair
@@ -1540,6 +1860,27 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
             const bool dbg = getenv("MI355_DEBUG") != nullptr && getenv("MI355_DEBUG")[0] == '2';
             double t_rys = 0.0, t_xf = 0.0;
+            // low angular classes: one thread per quartet, fused Rys + HRR + cart->sph + scatter (eri_tpq_kernel)
+            if (c->opt_eri_tpq) {
+                TpqArgs Q{};
+                Q.bra = B.d_recs; Q.ket = Kc.d_recs; Q.prim = c->d_prim; Q.prefix = d_prefix; Q.nbra = E.nbra; Q.t0 = 0; Q.ntask = ntask;
+                Q.c2s = c->d_c2s;
+                for (int q = 0; q <= LMAX + 1; q++) Q.c2s_off[q] = c->c2s_off[q];
+                Q.rys = c->rys; Q.X = X; Q.shell_xyz = c->d_shell_xyz; Q.check_owner = nranks > 1;
+                auto ta = std::chrono::steady_clock::now();
+                if (dbg) hipStreamSynchronize(st);
+                const int used = launch_eri_tpq(B.la, B.lb, Kc.la, Kc.lb, Q, st);
+                if (used < 0) return -1;
+                if (used) {
+                    if (dbg) {
+                        hipStreamSynchronize(st);
+                        t_rys = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+                        fprintf(stderr, "[mi355] eri class (%d%d|%d%d): %ld quartets, thread-per-quartet fused kernel %.4f s (%.2f ns/q)\n", B.la, B.lb,
+                                Kc.la, Kc.lb, (long)ntask, t_rys, t_rys / ntask * 1e9);
+                    }
+                    continue;
+                }
+            }
             for (int64_t t0 = 0; t0 < ntask; t0 += per) {
                 int nb = (int)std::min<int64_t>(per, ntask - t0);
                 E.t0 = t0; E.ntask = nb; X.t0 = t0;
