@@ -260,6 +260,7 @@ struct mi_ctx {
     int opt_jk_waves = 0;    // 0: one wave per work item, longest first; >0: that many waves, equal-cost shares
     int opt_jk_nt = 1;       // nontemporal loads for the tile stream
     double opt_grad_dtol = 1e-13; // gradient: skip quartets with q_ab q_cd max|G| below this (0: Schwarz only)
+    int opt_xf_mfma_min = 300; // transform kernel: MFMA tiles only when the spherical block has at least this many elements
     int opt_eri_tpq = 1;     // thread-per-quartet fused ERI kernels for the low angular classes (0: wave-per-quartet pair everywhere)
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
@@ -429,7 +430,8 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_nt") c->opt_jk_nt = (int)value;
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
-    else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;   // takes effect at the next mi_eri_prepare
+    else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;
+    else if (k == "xf_mfma_min") c->opt_xf_mfma_min = (int)value;   // takes effect at the next mi_eri_prepare
     else if (k == "grad_dtol") c->opt_grad_dtol = value;
     else return fail("mi_set_option: unknown key '%s'", key);
     return 0;
@@ -886,7 +888,7 @@ __device__ inline void put_tile(const XfArgs &A, int i, int j, int k, int l, dou
 // in eri_rys_kernel).  (Four waves sharing a quartet's LDS blocks were measured slower: 0.50 vs 0.46 s for
 // ibuprofen/def2-TZVP.)
 template <bool MFMA, int GSZ>
-__global__ __launch_bounds__(64) void eri_transform_scatter(XfArgs A)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void eri_transform_scatter(XfArgs A)
 {
     extern __shared__ double lds_all[];
     constexpr int QPW = 64 / GSZ;
@@ -1433,6 +1435,7 @@ static int launch_eri_tpq(int la, int lb, int lc, int ld, const TpqArgs &Q, hipS
         TPQ_CASE(2, 0, 0, 0); TPQ_CASE(2, 0, 1, 0); TPQ_CASE(2, 0, 1, 1); TPQ_CASE(2, 0, 2, 0); TPQ_CASE(2, 1, 0, 0);
         TPQ_CASE(2, 1, 1, 0); TPQ_CASE(2, 2, 0, 0); TPQ_CASE(3, 0, 0, 0); TPQ_CASE(3, 0, 1, 0); TPQ_CASE(3, 0, 2, 0);
         TPQ_CASE(3, 1, 0, 0); TPQ_CASE(3, 2, 0, 0);
+        TPQ_CASE(2, 1, 2, 0); TPQ_CASE(2, 2, 1, 0); TPQ_CASE(3, 3, 0, 0);   // 96 / 93 / 74 accumulators: one wave per SIMD, still ahead
     default: return 0;
     }
 #undef TPQ_CASE
@@ -1853,7 +1856,10 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             X.check_owner = nranks > 1; X.ni = E.ni; X.nj = E.nj; X.nk = E.nk; X.nl = E.nl;
             int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
             size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
-            const bool xf_mfma = mfma_worthwhile(X.nsab, X.nf, X.ne) || mfma_worthwhile(X.nsab, X.nscd, X.nf);
+            // matrix-core path only for the large classes: below, the lean per-lane kernel (56 VGPRs, 8 waves per SIMD) hides the
+            // per-quartet latency chain better than MFMA tiles at 3-4 waves per SIMD (measured per class on ibuprofen/def2-TZVP)
+            const bool xf_mfma = (mfma_worthwhile(X.nsab, X.nf, X.ne) || mfma_worthwhile(X.nsab, X.nscd, X.nf)) &&
+                                 X.nsab * X.nscd >= c->opt_xf_mfma_min;
             const bool xf_small = !xf_mfma && X.nsab * X.nscd <= 40 && shm2 * 4 <= 64 * 1024; // four quartets per wave
             if (shm2 > 64 * 1024)
                 HIPCHK(hipFuncSetAttribute(xf_mfma ? (const void *)eri_transform_scatter<true, 64> : (const void *)eri_transform_scatter<false, 64>,
