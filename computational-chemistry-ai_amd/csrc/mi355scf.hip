@@ -851,6 +851,11 @@ struct XfArgs {
     double *tiles;
     int nao;
     int check_owner, ni, nj, nk, nl;
+    // density fitting (mi_df_build): dense output instead of the tile scatter.  dense_mode 1: (ij|P) -> dense_out[i][j][P]
+    // and [j][i][P] (ld = dense_n auxiliary functions); 2: (P|Q) -> dense_out[P][Q] and [Q][P].  The fitted function of a
+    // "pair" (P, unit s) is its first shell.
+    double *dense_out;
+    int dense_mode, dense_n;
 };
 
 // Read-only, wave-uniform operands (work-item records, tile directory, the J-L density rows) go through the
@@ -922,6 +927,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     auto emit = [&](int r, int c, double s) {
         int sa = r / A.nsb, sb = r - sa * A.nsb, sc = c / A.nsd, sd = c - sc * A.nsd;
         int i = ab.ao_i + sa, j = ab.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
+        if (A.dense_mode == 1) {
+            A.dense_out[((size_t)i * A.nao + j) * A.dense_n + k] = s;
+            A.dense_out[((size_t)j * A.nao + i) * A.dense_n + k] = s;
+            return;
+        }
+        if (A.dense_mode == 2) {
+            A.dense_out[(size_t)i * A.dense_n + k] = s;
+            A.dense_out[(size_t)k * A.dense_n + i] = s;
+            return;
+        }
         if (mask & 1) put_tile(A, i, j, k, l, s);
         if (mask & 2) put_tile(A, j, i, k, l, s);
         if (mask & 4) put_tile(A, i, j, l, k, s);
@@ -1943,6 +1958,152 @@ extern "C" int mi_eri_get_memory(const mi_ctx *c, int64_t *need_bytes, int64_t *
     *need_bytes = c->mem_need_bytes;
     *free_bytes = c->mem_free_bytes;
     return 0;
+}
+
+// =================================================================================================
+// Density fitting: three-index (ij|P) and two-index (P|Q) Coulomb integrals over an auxiliary
+// basis with the SAME Rys kernels -- an auxiliary function P is handled as the "shell pair" (P, unit s function), i.e. a
+// four-centre quartet (ij|P 1).  Stands in for libcint int3c2e_sph / int2c2e_sph behind `mf.density_fit()` [MEM]; the
+// contractions with the density (J, K) are dense FP64 GEMMs done by the caller.
+// `aux` is an ordinary context built from the auxiliary basis whose LAST shell is the unit function: an s primitive with
+// exponent 0 and coefficient sqrt(4 pi) (so that coefficient * Y_00 = 1).
+// d_int3c: [nao][nao][naux] (both (i,j) and (j,i) written), d_int2c: [naux][naux]; either may be NULL.
+// =================================================================================================
+struct DfPairs {
+    std::vector<PairRec> recs[NPC];       // orbital shell pairs by class
+    std::vector<PairRec> aux[LMAX + 1];   // (P, unit) "pairs" by l_P
+    std::vector<double> prim, Mbuf;
+};
+
+extern "C" int mi_df_build(mi_ctx *c, mi_ctx *aux, double *d_int3c, double *d_int2c, void *stream)
+{
+    if (!c || !aux) return fail("mi_df_build: null context");
+    if (aux->nbas < 2) return fail("mi_df_build: the auxiliary context needs at least one function plus the unit shell");
+    const ShellH &U = aux->shells.back();
+    if (U.l != 0 || U.nprim != 1 || U.exps[0] != 0.0) return fail("mi_df_build: the last auxiliary shell must be the unit s function (exponent 0)");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int naux = aux->nao - 1, unit_ao = aux->nao - 1, nP = aux->nbas - 1;
+    std::vector<std::vector<double>> c2s(LMAX + 1);
+    for (int l = 0; l <= LMAX; l++) c2s_generic(l, c2s[l]);
+    DfPairs D;
+    // orbital pairs (as in mi_eri_prepare step 1, no Schwarz sorting: every pair is fitted)
+    for (int A = 0; A < c->nbas; A++)
+        for (int B = 0; B <= A; B++) {
+            int si = A, sj = B;
+            if (c->shells[si].l < c->shells[sj].l) std::swap(si, sj);
+            const ShellH &I = c->shells[si], &J = c->shells[sj];
+            double AB[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+            double r2 = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
+            PairRec R{si, sj, I.ao, J.ao, (int)(D.prim.size() / 8), 0, 0, 0};
+            for (int ip = 0; ip < I.nprim; ip++)
+                for (int jp = 0; jp < J.nprim; jp++) {
+                    double a = I.exps[ip], b = J.exps[jp], p = a + b, mu = a * b / p;
+                    if (mu * r2 > 80.0) continue;
+                    double K = I.coef[ip] * J.coef[jp] * std::exp(-mu * r2), Pc[3];
+                    for (int d = 0; d < 3; d++) Pc[d] = (a * I.r[d] + b * J.r[d]) / p;
+                    double rec[8] = {p, Pc[0], Pc[1], Pc[2], Pc[0] - I.r[0], Pc[1] - I.r[1], Pc[2] - I.r[2], K};
+                    D.prim.insert(D.prim.end(), rec, rec + 8);
+                    R.nprim++;
+                }
+            if (R.nprim == 0) continue;
+            const int nsab = (2 * I.l + 1) * (2 * J.l + 1), ne = ne_of(I.l, J.l);
+            R.m_off = (int)D.Mbuf.size();
+            D.Mbuf.resize(D.Mbuf.size() + (size_t)2 * nsab * ne);
+            build_M(I.l, J.l, AB, c2s[I.l], c2s[J.l], D.Mbuf.data() + R.m_off);
+            double *M = D.Mbuf.data() + R.m_off, *Mt = M + (size_t)nsab * ne;
+            for (int r = 0; r < nsab; r++)
+                for (int e = 0; e < ne; e++) Mt[(size_t)e * nsab + r] = M[(size_t)r * ne + e];
+            D.recs[pc_index(I.l, J.l)].push_back(R);
+        }
+    // auxiliary "pairs" (P, unit): p = alpha, centre P = A, P - A = 0, K = c_P * c_unit
+    for (int Pn = 0; Pn < nP; Pn++) {
+        const ShellH &S = aux->shells[Pn];
+        PairRec R{Pn, aux->nbas - 1, S.ao, unit_ao, (int)(D.prim.size() / 8), S.nprim, 0, 0};
+        for (int ip = 0; ip < S.nprim; ip++) {
+            double rec[8] = {S.exps[ip], S.r[0], S.r[1], S.r[2], 0.0, 0.0, 0.0, S.coef[ip] * U.coef[0]};
+            D.prim.insert(D.prim.end(), rec, rec + 8);
+        }
+        const int ns = 2 * S.l + 1, ne = ncart(S.l);
+        double AB[3] = {0.0, 0.0, 0.0};
+        R.m_off = (int)D.Mbuf.size();
+        D.Mbuf.resize(D.Mbuf.size() + (size_t)2 * ns * ne);
+        build_M(S.l, 0, AB, c2s[S.l], c2s[0], D.Mbuf.data() + R.m_off);
+        double *M = D.Mbuf.data() + R.m_off, *Mt = M + (size_t)ns * ne;
+        for (int r = 0; r < ns; r++)
+            for (int e = 0; e < ne; e++) Mt[(size_t)e * ns + r] = M[(size_t)r * ne + e];
+        // c2s of the unit function: build_M multiplied by c2s[0] = 1/sqrt(4 pi); its coefficient sqrt(4 pi) restores 1
+        D.aux[S.l].push_back(R);
+    }
+    if (D.Mbuf.size() > (size_t)INT32_MAX) return fail("mi_df_build: transformation-matrix buffer exceeds 2^31 doubles");
+    double *d_prim = nullptr, *d_M = nullptr, *d_work = nullptr;
+    uint32_t *d_comp = nullptr;
+    int64_t *d_prefix = nullptr;
+    PairRec *d_rec_o[NPC] = {nullptr}, *d_rec_a[LMAX + 1] = {nullptr};
+    if (upload(&d_prim, D.prim) || upload(&d_M, D.Mbuf)) return -1;
+    for (int q = 0; q < NPC; q++) if (!D.recs[q].empty() && upload(&d_rec_o[q], D.recs[q])) return -1;
+    for (int l = 0; l <= LMAX; l++) if (!D.aux[l].empty() && upload(&d_rec_a[l], D.aux[l])) return -1;
+    const size_t WORK_DOUBLES = (size_t)32 << 20;
+    HIPCHK(hipMalloc(&d_work, sizeof(double) * WORK_DOUBLES));
+    HIPCHK(hipMalloc(&d_comp, sizeof(uint32_t) * 8192));
+    size_t prefix_cap = 0;
+    // one pass per (bra class, auxiliary l): bra = orbital pairs (3-index) or auxiliary pairs (2-index)
+    auto run = [&](const PairRec *d_bra, int nbra, int la, int lb, int lk, int mode, double *out, int ld_nao) -> int {
+        const int nket = (int)D.aux[lk].size();
+        if (nbra == 0 || nket == 0) return 0;
+        std::vector<int64_t> prefix(nbra + 1);
+        for (int b = 0; b <= nbra; b++) prefix[b] = (int64_t)b * nket;
+        const int64_t ntask = prefix.back();
+        append_coarse_index(prefix);
+        if (prefix.size() > prefix_cap) {
+            if (d_prefix) hipFree(d_prefix);
+            prefix_cap = prefix.size() * 2;
+            HIPCHK(hipMalloc(&d_prefix, sizeof(int64_t) * prefix_cap));
+        }
+        HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
+        EriArgs E{};
+        setup_eri_dims(E, la, lb, lk, 0);
+        std::vector<uint32_t> comp;
+        build_comp_table(la, lb, lk, 0, comp);
+        HIPCHK(hipMemcpyAsync(d_comp, comp.data(), sizeof(uint32_t) * comp.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        E.bra = d_bra; E.ket = d_rec_a[lk]; E.prim = d_prim; E.prefix = d_prefix; E.nbra = nbra;
+        E.comp = d_comp; E.work = d_work; E.rys = c->rys; E.diag = 0;
+        E.ni = 2 * la + 1; E.nj = 2 * lb + 1; E.nk = 2 * lk + 1; E.nl = 1;
+        XfArgs X{};
+        X.bra = d_bra; X.ket = d_rec_a[lk]; X.Mbuf = d_M; X.prefix = d_prefix; X.nbra = nbra;
+        X.ne = ne_of(la, lb); X.nf = ncart(lk); X.nsab = (2 * la + 1) * (2 * lb + 1); X.nscd = 2 * lk + 1; X.nsb = 2 * lb + 1; X.nsd = 1;
+        X.work = d_work; X.ncomp = E.ncomp; X.nao = ld_nao; X.check_owner = 0;
+        X.ni = E.ni; X.nj = E.nj; X.nk = E.nk; X.nl = 1;
+        X.dense_out = out; X.dense_mode = mode; X.dense_n = naux;
+        const size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
+        const int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
+        for (int64_t t0 = 0; t0 < ntask; t0 += per) {
+            const int nb = (int)std::min<int64_t>(per, ntask - t0);
+            E.t0 = t0; E.ntask = nb; X.t0 = t0; X.ntask = nb;
+            if (launch_eri(c, E, nb, st)) return -1;
+            hipLaunchKernelGGL((eri_transform_scatter<false, 64>), dim3(nb), dim3(64), shm2, st, X);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    };
+    int rc = 0;
+    if (d_int3c)
+        for (int la = 0; la <= LMAX && !rc; la++)
+            for (int lb = 0; lb <= la && !rc; lb++)
+                for (int lk = 0; lk <= LMAX && !rc; lk++) {
+                    const int q = pc_index(la, lb);
+                    rc = run(d_rec_o[q], (int)D.recs[q].size(), la, lb, lk, 1, d_int3c, c->nao);
+                }
+    if (d_int2c)
+        for (int lp = 0; lp <= LMAX && !rc; lp++)
+            for (int lk = 0; lk <= LMAX && !rc; lk++) rc = run(d_rec_a[lp], (int)D.aux[lp].size(), lp, 0, lk, 2, d_int2c, naux);
+    for (int q = 0; q < NPC; q++) if (d_rec_o[q]) hipFree(d_rec_o[q]);
+    for (int l = 0; l <= LMAX; l++) if (d_rec_a[l]) hipFree(d_rec_a[l]);
+    hipFree(d_prim); hipFree(d_M); hipFree(d_work); hipFree(d_comp);
+    if (d_prefix) hipFree(d_prefix);
+    return rc;
 }
 
 extern "C" int mi_eri_get_stats(const mi_ctx *c, mi_eri_stats *out)

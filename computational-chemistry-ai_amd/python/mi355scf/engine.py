@@ -94,6 +94,7 @@ def lib():
         L.mi_eri_get_memory.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.mi_eri_read_quartet.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
         L.mi_schwarz_get.argtypes = [vp, dp]
+        L.mi_df_build.argtypes = [vp, vp, vp, vp, vp]
         L.mi_reduce_blocks.argtypes = [vp]
         L.mi_plan_shards.argtypes = [ctypes.c_int, dp, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
                                      ctypes.POINTER(ctypes.c_int64)]
@@ -262,6 +263,13 @@ class Engine:
             J = J[0] if with_j else None
             K = K[0] if with_k else None
         return J, K
+
+    def df_build(self, aux_engine, int3c, int2c):
+        """(ij|P) -> int3c[nao, nao, naux], (P|Q) -> int2c[naux, naux]; `aux_engine`: context of the auxiliary basis whose last
+        shell is the unit function (see `df.DF.build`)."""
+        with torch.cuda.device(self.device):
+            _check(lib().mi_df_build(self._h, aux_engine._h, int3c.data_ptr() if int3c is not None else None,
+                                     int2c.data_ptr() if int2c is not None else None, self._stream()))
 
     def eri_dense(self):
         """(ij|kl) as a dense [nao]*4 device tensor (small molecules only: 8 nao^4 bytes)."""

@@ -73,6 +73,8 @@ class Gradients:
 
     def kernel(self, mo_energy=None, mo_coeff=None, mo_occ=None, atmlst=None):
         mf = self.base
+        if getattr(mf, "with_df", None) is not None:
+            raise NotImplementedError("analytic gradients of density-fitted SCF are not implemented (use the exact-integral SCF)")
         if mf._dm is None or not mf.converged:
             mf.kernel()
         eng = mf.engine

@@ -242,7 +242,16 @@ class SCF:
         L = torch.linalg.cholesky(S)
         self._L = L
         self._Linv = torch.linalg.solve_triangular(L, torch.eye(eng.nao, dtype=torch.float64, device=eng.device), upper=False)
-        if not eng.eri_ready and self._stream_groups <= 1:
+        if getattr(self, "with_df", None) is not None:
+            if self.with_df.mol is not self.mol or self.with_df._B is None:
+                self.with_df.mol = self.mol
+                t1 = time.time()
+                self.with_df.build(eng)
+                torch.cuda.synchronize()
+                self.timing["df_seconds"] = time.time() - t1
+                self._log(4, f"density fitting: {self.with_df.naux} auxiliary functions, tensor "
+                             f"{8e-9 * self.with_df.naux * eng.nao ** 2:.2f} GB, built in {self.timing['df_seconds']:.3f} s")
+        elif not eng.eri_ready and self._stream_groups <= 1:
             try:
                 st = eng.prepare_eri(self.direct_scf_tol, self._rank, self._nranks)
                 self.timing["eri_seconds"] = st["seconds_eri"]
@@ -279,6 +288,8 @@ class SCF:
         return J, K   # pair records / Schwarz data of the last group stay valid (used by the gradient)
 
     def _jk(self, dm, with_j=True, with_k=True):
+        if getattr(self, "with_df", None) is not None:     # fitted integrals: dense GEMMs on the resident B tensor, replicated
+            return self.with_df.get_jk(dm, with_j, with_k)
         if self._stream_groups > 1:
             J, K = self._jk_streamed(dm, with_j, with_k)
         else:
@@ -295,6 +306,13 @@ class SCF:
     def _jk_into(self, dm, J, K):
         """This rank's PARTIAL J (and K unless None) written into caller-owned views, no collective: the caller all-reduces
         the buffer the views live in (Kohn-Sham: one fused [J|K|Vxc|N|Exc] collective per Fock build)."""
+        if getattr(self, "with_df", None) is not None:
+            j, k = self.with_df.get_jk(dm, True, K is not None)
+            scale = 1.0 / self._nranks       # replicated fit: every rank adds its share so that the all-reduce restores J, K
+            J.copy_(j * scale)
+            if K is not None:
+                K.copy_(k * scale)
+            return
         if self._stream_groups > 1:
             j, k = self._jk_streamed(dm, True, K is not None)
             J.copy_(j)
@@ -737,11 +755,14 @@ class SCF:
             self._log(3, "Dipole moment(X, Y, Z, A.U.): %8.5f, %8.5f, %8.5f" % tuple(out))
         return out
 
-    def density_fit(self, auxbasis=None, **kw):
-        """PySCF idiom `mf.density_fit()` (never called by the reference).  This engine keeps
-        the exact four-centre ERIs resident instead of fitting them, so the call is accepted and changes nothing; results
-        are the un-fitted ones (a density-fitted PySCF run differs from them by its fitting error, 1e-5..1e-4 Ha)."""
-        self._log(3, "density_fit(): not applied -- exact four-centre integrals are used (resident ERI tiles)")
+    def density_fit(self, auxbasis=None, with_df=None, only_dfj=False, **kw):
+        """PySCF idiom `mf.density_fit()` (never called by the reference): J and K from a fitted
+        three-index tensor (`df.DF`) instead of the resident four-centre tiles.  `auxbasis`: None -> generated even-tempered
+        set, or a {element: shells} dict.  Returns `self` (PySCF returns a DF-decorated copy; the templates' idiom
+        `mf = mf.density_fit()` works with both)."""
+        from . import df
+        self.with_df = with_df if with_df is not None else df.DF(self.mol, auxbasis)
+        self._eng_df_ready = False
         return self
 
     def nuc_grad_method(self):

@@ -78,6 +78,13 @@ int mi_eri_get_memory(const mi_ctx *ctx, int64_t *need_bytes, int64_t *free_byte
  * ("deal cost-balanced batches").  Outputs: bytes and runs per rank. */
 int mi_plan_shards(int nao, const double *qblk, double tol, int nranks, int64_t *bytes_per_rank, int64_t *runs_per_rank);
 
+/* Density fitting (`mf.density_fit()`): three-index (ij|P) and two-index (P|Q) Coulomb
+ * integrals over the auxiliary basis held by the context `aux` -- an ordinary context (mi_ctx_create on the auxiliary
+ * atm/bas/env) whose LAST shell is the unit function (s primitive, exponent 0, coefficient sqrt(4 pi)).  Evaluated by the same
+ * Rys kernels as the four-centre integrals ((ij|P 1) quartets).  d_int3c[nao][nao][naux], d_int2c[naux][naux], naux =
+ * mi_ctx_nao(aux) - 1; either may be NULL.  Replaces libcint int3c2e_sph / int2c2e_sph behind pyscf.df [MEM]. */
+int mi_df_build(mi_ctx *ctx, mi_ctx *aux, double *d_int3c, double *d_int2c, void *stream);
+
 /* Schwarz factors of the last mi_eri_prepare: q[nbas][nbas] (host), q_ab = sqrt(max |(ab|ab)|), 0 for dropped pairs.
  * Replaces: libcvhf CVHFnr_int2e_q_cond [MEM]. */
 int mi_schwarz_get(const mi_ctx *ctx, double *q);

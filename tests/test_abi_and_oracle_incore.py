@@ -101,3 +101,26 @@ def test_lpt_shard_plan_c60_balanced_and_exhaustive():
     q2 = _block_schwarz(m2, orc.Oracle(m2).schwarz())
     b, r = engine.plan_shards(m2.nao, q2, 1e-13, 3)
     assert b.sum() == engine.plan_shards(m2.nao, q2, 1e-13, 1)[0][0] and (b.max() - b.min()) / b.mean() < 0.02
+
+
+def test_oracle_density_fitting_restatement():
+    """oracle/df.py (checker of `mf.density_fit()`): (ij|P), (P|Q) through the unit-function trick are symmetric / positive and
+    the fitted J, K approach the exact ones from below in the Coulomb metric (robust fit: the error in the self-repulsion
+    energy is negative semi-definite)."""
+    from mi355scf import df
+    from mi355scf.mole import Mole
+    from oracle import df as odf
+    from oracle import oracle as orc
+    mol = _mol("h2o", "6-31g")
+    aux = Mole(atom=[(s, xyz) for s, xyz in mol._atom], basis=df.even_tempered_aux(mol, 2.0), unit="Bohr", verbose=0).build()
+    assert aux.nao > 2 * mol.nao and (aux._bas[:, 1] <= 3).all()
+    j3, j2 = odf.integrals(mol, aux)
+    assert np.abs(j2 - j2.T).max() < 1e-12 and np.linalg.eigvalsh(j2).min() > 0
+    assert np.abs(j3 - j3.transpose(1, 0, 2)).max() < 1e-12
+    r = orc.rhf(mol)
+    D = r["dm"]
+    J, K = odf.jk(j3, j2, D)
+    Je, Ke = orc.Oracle(mol).jk(D, tol=0.0)
+    ej, eje = 0.5 * np.sum(D * J), 0.5 * np.sum(D * Je)
+    assert -5e-4 < ej - eje <= 1e-10            # fitted Coulomb energy: below the exact one, by little
+    assert np.abs(J - Je).max() < 5e-3 and np.abs(K - Ke).max() < 5e-3
