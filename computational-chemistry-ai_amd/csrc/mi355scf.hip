@@ -2948,7 +2948,8 @@ template <int N> __device__ inline DN<N> dasinh(DN<N> a) { return chain(a, asinh
 typedef DN<2> D2;
 typedef DN<5> D5;
 
-enum { XC_SLATER = 1, XC_B88 = 2, XC_VWN_RPA = 3, XC_VWN5 = 4, XC_LYP = 5, XC_PBE_X = 6, XC_PBE_C = 7 };
+enum { XC_SLATER = 1, XC_B88 = 2, XC_VWN_RPA = 3, XC_VWN5 = 4, XC_LYP = 5, XC_PBE_X = 6, XC_PBE_C = 7,
+       XC_TPSS_X = 8, XC_TPSS_C = 9, XC_M062X_X = 10, XC_M062X_C = 11 };   // 8..11: meta-GGA (need tau)
 
 // ---- closed-shell energy densities per volume e(rho, sigma); T is a dual-number type
 template <class T> __device__ inline T f_slater(T rho) { return T(-0.7385587663820224) * dpow(rho, 4.0 / 3.0); } // -(3/4)(3/pi)^(1/3)
@@ -3106,6 +3107,157 @@ template <class T> __device__ inline T f_pbe_c_spin(T ra, T rb, T saa, T sab, T 
     return rho * (ec + H);
 }
 
+// =================================================================================================
+// meta-GGA functionals (`--method M06-2X` at templates/calculate_energy.py:263, the default of
+// templates/calculate_bde.py:105,502).  Spin-resolved energy densities per volume e(rho_a, rho_b, sigma_aa, sigma_ab,
+// sigma_bb, tau_a, tau_b), tau_s = 1/2 sum_i |grad phi_i,s|^2, coded once on the dual-number type; the closed-shell kernel
+// calls them with rho_s = rho/2, sigma_ss' = sigma/4, tau_s = tau/2.
+//   TPSS      Tao, Perdew, Staroverov, Scuseria, PRL 91, 146401 (2003): exchange eq. 10, correlation = revPKZB (eqs. 11-14)
+//   M06-2X    Zhao, Truhlar, Theor. Chem. Acc. 120, 215 (2008): PBE-exchange x kinetic-energy-density series (the VS98-type
+//             exchange term is zero for M06-2X), M05-type + VS98-type correlation; 54 % exact exchange.
+// PARAMETER TABLES ENTERED FROM MEMORY (no libxc here): "unverified-memory".  What IS checked (tests): the uniform-gas limit
+// (a_0 + X = 1, c_0 + d_0 = 1 for both correlation channels), vanishing correlation and the exact TPSS exchange energy for
+// one-electron densities, derivatives against the complex-step oracle.
+// =================================================================================================
+template <class T> __device__ inline T dmaxv(T a, T b) { return a.v >= b.v ? a : b; }
+
+// PW92 correlation energy per particle of the spin-polarised uniform gas
+template <class T> __device__ inline T pw92_eps_spin(T ra, T rb)
+{
+    T rho = ra + rb;
+    T rs = dpow(T(0.75 / M_PI) / rho, 1.0 / 3.0);
+    T e0 = pw92_g(rs, 0.031090690869654895, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+    T e1 = pw92_g(rs, 0.015545345434827448, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+    T mac = pw92_g(rs, 0.016886863940389627, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);
+    T z = spin_zeta(ra, rb), fz = spin_fzeta(z), z4 = z * z * z * z;
+    return e0 - mac * fz * T(1.0 / 1.7099209341613657) * (T(1.0) - z4) + (e1 - e0) * fz * z4;
+}
+
+// ---- TPSS exchange of a spin-UNpolarised density (rho, sigma = |grad rho|^2, tau); spin scaling handles the rest
+template <class T> __device__ inline T f_tpss_x_unpol(T rho, T sig, T tau)
+{
+    const double kappa = 0.804, bb = 0.40, cc = 1.59096, ee = 1.537, mu = 0.21951, se = 1.2397580409105368 /* sqrt(e) */;
+    T p = sig / (T(4.0 * 9.570780000627305 /* (3 pi^2)^(2/3) */) * dpow(rho, 8.0 / 3.0));
+    T tw = sig / (T(8.0) * rho);
+    T z = tw / tau;
+    if (z.v > 1.0) z = T(1.0);                                   // tau_W <= tau for N-representable input
+    T tunif = T(0.3 * 9.570780000627305) * dpow(rho, 5.0 / 3.0);
+    T alpha = (tau - tw) / tunif;
+    if (alpha.v < 0.0) alpha = T(0.0);
+    T qb = T(0.45) * (alpha - T(1.0)) / dsqrt(T(1.0) + T(bb) * alpha * (alpha - T(1.0))) + T(2.0 / 3.0) * p;
+    T z2 = z * z;
+    T t1 = (T(10.0 / 81.0) + T(cc) * z2 / ((T(1.0) + z2) * (T(1.0) + z2))) * p;
+    T t2 = T(146.0 / 2025.0) * qb * qb;
+    T t3 = T(-73.0 / 405.0) * qb * dsqrt(T(0.5) * (T(0.6) * z) * (T(0.6) * z) + T(0.5) * p * p + T(1e-300));
+    T t4 = T((10.0 / 81.0) * (10.0 / 81.0) / kappa) * p * p;
+    T t5 = T(2.0 * se * (10.0 / 81.0)) * (T(0.6) * z) * (T(0.6) * z);
+    T t6 = T(ee * mu) * p * p * p;
+    T den = T(1.0) + T(se) * p;
+    T x = (t1 + t2 + t3 + t4 + t5 + t6) / (den * den);
+    T Fx = T(1.0 + kappa) - T(kappa) / (T(1.0) + x / T(kappa));
+    return f_slater(rho) * Fx;
+}
+template <class T> __device__ inline T f_tpss_x_spin(T ra, T rb, T saa, T sbb, T ta, T tb)
+{
+    T e(0.0);
+    if (ra.v > 1e-12 && ta.v > 1e-14) e = e + T(0.5) * f_tpss_x_unpol(T(2.0) * ra, T(4.0) * saa, T(2.0) * ta);
+    if (rb.v > 1e-12 && tb.v > 1e-14) e = e + T(0.5) * f_tpss_x_unpol(T(2.0) * rb, T(4.0) * sbb, T(2.0) * tb);
+    return e;
+}
+// ---- TPSS correlation (revPKZB)
+template <class T> __device__ inline T f_tpss_c_spin(T ra, T rb, T saa, T sab, T sbb, T ta, T tb)
+{
+    const double d = 2.8;
+    T rho = ra + rb, sig = saa + T(2.0) * sab + sbb, tau = ta + tb;
+    if (tau.v < 1e-14) return T(0.0);
+    T tw = sig / (T(8.0) * rho);
+    T z = tw / tau;
+    if (z.v > 1.0) z = T(1.0);
+    T zeta = spin_zeta(ra, rb);
+    // xi = |grad zeta| / (2 (3 pi^2 rho)^(1/3)),  |grad zeta|^2 = 4 (rb^2 saa - 2 ra rb sab + ra^2 sbb) / rho^4
+    T gz2 = T(4.0) * (rb * rb * saa - T(2.0) * ra * rb * sab + ra * ra * sbb) / (rho * rho * rho * rho);
+    if (gz2.v < 0.0) gz2 = T(0.0);
+    T xi2 = gz2 / (T(4.0) * dpow(T(3.0 * M_PI * M_PI) * rho, 2.0 / 3.0));
+    T z2_ = zeta * zeta;
+    T C0 = T(0.53) + T(0.87) * z2_ + T(0.50) * z2_ * z2_ + T(2.26) * z2_ * z2_ * z2_;
+    T den = T(1.0) + xi2 * T(0.5) * (dpow(T(1.0) + zeta, -4.0 / 3.0) + dpow(T(1.0) - zeta, -4.0 / 3.0));
+    T den2 = den * den;
+    T C = C0 / (den2 * den2);
+    T epbe = f_pbe_c_spin(ra, rb, saa, sab, sbb) / rho;
+    T ea = epbe, eb = epbe;
+    if (ra.v > 1e-12) ea = dmaxv(f_pbe_c_spin(ra, T(0.0), saa, T(0.0), T(0.0)) / ra, epbe);
+    if (rb.v > 1e-12) eb = dmaxv(f_pbe_c_spin(rb, T(0.0), sbb, T(0.0), T(0.0)) / rb, epbe);
+    T zz = z * z;
+    T erev = epbe * (T(1.0) + C * zz) - (T(1.0) + C) * zz * (ra / rho * ea + rb / rho * eb);
+    return rho * erev * (T(1.0) + T(d) * erev * zz * z);
+}
+
+// ---- M06-2X.  Parameter tables: unverified-memory (see the header of this block).
+__device__ __constant__ double M062X_A[12] = {4.600000e-01, -2.206052e-01, -9.431788e-02, 2.164494e+00, -2.556466e+00, -1.422133e+01,
+                                              1.555044e+01, 3.598078e+01, -2.722754e+01, -3.924093e+01, 1.522808e+01, 1.522227e+01};
+__device__ __constant__ double M062X_CSS[5] = {3.097855e-01, -5.528642e+00, 1.347420e+01, -3.213623e+01, 2.846742e+01};
+__device__ __constant__ double M062X_CAB[5] = {8.833596e-01, 3.357972e+01, -7.043548e+01, 4.978271e+01, -1.852891e+01};
+__device__ __constant__ double M062X_DSS[6] = {6.902145e-01, 9.847204e-02, 2.214797e-01, -1.968264e-03, -6.775479e-03, 0.0};
+__device__ __constant__ double M062X_DAB[6] = {1.166404e-01, -9.120847e-02, -6.726189e-02, 6.720580e-05, 8.448011e-04, 0.0};
+#define M06_CF 9.115599744691194 /* (3/5)(6 pi^2)^(2/3) */
+
+template <class T> __device__ inline T f_m06_x_channel(T r, T s, T tau, const double *a) // one spin channel: r = rho_s
+{
+    T tl = T(0.3 * 15.192666241151989 /* (6 pi^2)^(2/3) */) * dpow(r, 5.0 / 3.0);
+    T t = tl / tau;
+    T w = (t - T(1.0)) / (t + T(1.0));
+    T fw(a[11]);
+#pragma unroll
+    for (int i = 10; i >= 0; i--) fw = fw * w + T(a[i]);
+    return T(0.5) * f_pbe_x(T(2.0) * r, T(4.0) * s) * fw;
+}
+template <class T> __device__ inline T f_m062x_x_spin(T ra, T rb, T saa, T sbb, T ta, T tb)
+{
+    T e(0.0);
+    if (ra.v > 1e-12 && ta.v > 1e-14) e = e + f_m06_x_channel(ra, saa, ta, M062X_A);
+    if (rb.v > 1e-12 && tb.v > 1e-14) e = e + f_m06_x_channel(rb, sbb, tb, M062X_A);
+    return e;
+}
+template <class T> __device__ inline T m06_h(T x2, T z, const double *dc, double alpha)
+{
+    T g = T(1.0) + T(alpha) * (x2 + z);
+    return T(dc[0]) / g + (T(dc[1]) * x2 + T(dc[2]) * z) / (g * g) + (T(dc[3]) * x2 * x2 + T(dc[4]) * x2 * z + T(dc[5]) * z * z) / (g * g * g);
+}
+template <class T> __device__ inline T m06_g(T x2, const double *cc, double gamma)
+{
+    T u = T(gamma) * x2 / (T(1.0) + T(gamma) * x2);
+    T g(cc[4]);
+#pragma unroll
+    for (int i = 3; i >= 0; i--) g = g * u + T(cc[i]);
+    return g;
+}
+template <class T> __device__ inline T f_m062x_c_spin(T ra, T rb, T saa, T sbb, T ta, T tb)
+{
+    const bool ha = ra.v > 1e-12 && ta.v > 1e-14, hb = rb.v > 1e-12 && tb.v > 1e-14;
+    T e(0.0), ess_a(0.0), ess_b(0.0), x2a(0.0), x2b(0.0), za(0.0), zb(0.0);
+    if (ha) {
+        x2a = saa / dpow(ra, 8.0 / 3.0);
+        za = T(2.0) * ta / dpow(ra, 5.0 / 3.0) - T(M06_CF);
+        ess_a = ra * pw92_eps_spin(ra, T(0.0));
+        T Dsic = T(1.0) - x2a / (T(4.0) * (za + T(M06_CF)));
+        if (Dsic.v < 0.0) Dsic = T(0.0);
+        e = e + ess_a * (m06_g(x2a, M062X_CSS, 0.06) + m06_h(x2a, za, M062X_DSS, 0.00515088)) * Dsic;
+    }
+    if (hb) {
+        x2b = sbb / dpow(rb, 8.0 / 3.0);
+        zb = T(2.0) * tb / dpow(rb, 5.0 / 3.0) - T(M06_CF);
+        ess_b = rb * pw92_eps_spin(rb, T(0.0));
+        T Dsic = T(1.0) - x2b / (T(4.0) * (zb + T(M06_CF)));
+        if (Dsic.v < 0.0) Dsic = T(0.0);
+        e = e + ess_b * (m06_g(x2b, M062X_CSS, 0.06) + m06_h(x2b, zb, M062X_DSS, 0.00515088)) * Dsic;
+    }
+    if (ha && hb) {
+        T eab = (ra + rb) * pw92_eps_spin(ra, rb) - ess_a - ess_b;
+        e = e + eab * (m06_g(x2a + x2b, M062X_CAB, 0.0031) + m06_h(x2a + x2b, za + zb, M062X_DAB, 0.00304966));
+    }
+    return e;
+}
+
 struct XcSpec { int n; int kind[8]; double coef[8]; };
 
 // exc[g] = e(rho,sigma) per volume; wv[0] = 0.5 w de/drho ; wv[1..3] = 2 w de/dsigma * grad rho
@@ -3224,6 +3376,125 @@ extern "C" int mi_xc_eval(const int32_t *kinds, const double *coefs, int nterms,
     }
     hipLaunchKernelGGL(xc_eval_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, d_rho, d_w, ng, gga,
                        d_exc, d_wv, d_vrho, d_vsigma);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- meta-GGA evaluation.  Closed shell: rho[0..3] = density and gradient, tau = 1/2 sum_i |grad phi_i|^2 (all electrons);
+// wv[0] = 0.5 w de/drho, wv[1..3] = 2 w de/dsigma grad rho, wv[4] = 0.25 w de/dtau  (V = vmat + vmat^T with
+// vmat = ao0^T (wv0 ao0 + wv_k ao_k) + sum_k ao_k^T (wv4 ao_k)).
+typedef DN<3> D3;
+typedef DN<7> D7;
+template <class T>
+__device__ inline T xc_term_spin(int kind, T Ra, T Rb, T Saa, T Sab, T Sbb, T Ta, T Tb)
+{
+    switch (kind) {
+    case XC_SLATER: return spin_scaled_exchange(Ra, Rb, Saa, Sbb, [](T r, T) { return f_slater(r); });
+    case XC_B88: return spin_scaled_exchange(Ra, Rb, Saa, Sbb, [](T r, T s_) { return f_b88(r, s_); });
+    case XC_PBE_X: return spin_scaled_exchange(Ra, Rb, Saa, Sbb, [](T r, T s_) { return f_pbe_x(r, s_); });
+    case XC_VWN_RPA: return f_vwn_rpa_spin(Ra, Rb);
+    case XC_VWN5: return f_vwn5_spin(Ra, Rb);
+    case XC_LYP: return f_lyp_spin(Ra, Rb, Saa, Sab, Sbb);
+    case XC_PBE_C: return f_pbe_c_spin(Ra, Rb, Saa, Sab, Sbb);
+    case XC_TPSS_X: return f_tpss_x_spin(Ra, Rb, Saa, Sbb, Ta, Tb);
+    case XC_TPSS_C: return f_tpss_c_spin(Ra, Rb, Saa, Sab, Sbb, Ta, Tb);
+    case XC_M062X_X: return f_m062x_x_spin(Ra, Rb, Saa, Sbb, Ta, Tb);
+    case XC_M062X_C: return f_m062x_c_spin(Ra, Rb, Saa, Sbb, Ta, Tb);
+    default: return T(0.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void xc_eval_mgga_kernel(XcSpec X, const double *rho, const double *tau, const double *w, int64_t ng,
+                                                           double *exc, double *wv)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const double r = rho[g], gx = rho[ng + g], gy = rho[2 * ng + g], gz = rho[3 * ng + g], t = tau[g];
+    double e = 0.0, vr = 0.0, vs = 0.0, vt = 0.0;
+    if (r > 1e-10) {
+        D3 R = D3::var(r, 0), S = D3::var(gx * gx + gy * gy + gz * gz, 1), Tt = D3::var(fmax(t, 0.0), 2);
+        D3 Rh = R * D3(0.5), S4 = S * D3(0.25), Th = Tt * D3(0.5);
+        D3 acc(0.0);
+        for (int q = 0; q < X.n; q++) acc = acc + D3(X.coef[q]) * xc_term_spin(X.kind[q], Rh, Rh, S4, S4, S4, Th, Th);
+        e = acc.v; vr = acc.d[0]; vs = acc.d[1]; vt = acc.d[2];
+    }
+    if (exc) exc[g] = e;
+    if (wv) {
+        const double ww = w[g], f = 2.0 * ww * vs;
+        wv[g] = 0.5 * ww * vr;
+        wv[ng + g] = f * gx; wv[2 * ng + g] = f * gy; wv[3 * ng + g] = f * gz;
+        wv[4 * ng + g] = 0.25 * ww * vt;
+    }
+}
+
+__global__ __launch_bounds__(256) void xc_eval_mgga_spin_kernel(XcSpec X, const double *rhoa, const double *rhob, const double *taua,
+                                                                const double *taub, const double *w, int64_t ng, double *exc, double *wva,
+                                                                double *wvb)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const double ra = fmax(rhoa[g], 0.0), rb = fmax(rhob[g], 0.0);
+    double ga[3], gb[3];
+    for (int k = 0; k < 3; k++) { ga[k] = rhoa[(k + 1) * ng + g]; gb[k] = rhob[(k + 1) * ng + g]; }
+    double e = 0.0, v[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (ra + rb > 1e-10) {
+        D7 Ra = D7::var(ra, 0), Rb = D7::var(rb, 1);
+        D7 Saa = D7::var(ga[0] * ga[0] + ga[1] * ga[1] + ga[2] * ga[2], 2);
+        D7 Sab = D7::var(ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2], 3);
+        D7 Sbb = D7::var(gb[0] * gb[0] + gb[1] * gb[1] + gb[2] * gb[2], 4);
+        D7 Ta = D7::var(fmax(taua[g], 0.0), 5), Tb = D7::var(fmax(taub[g], 0.0), 6);
+        D7 acc(0.0);
+        for (int q = 0; q < X.n; q++) acc = acc + D7(X.coef[q]) * xc_term_spin(X.kind[q], Ra, Rb, Saa, Sab, Sbb, Ta, Tb);
+        e = acc.v;
+        for (int k = 0; k < 7; k++) v[k] = acc.d[k];
+    }
+    if (exc) exc[g] = e;
+    const double ww = w[g];
+    wva[g] = 0.5 * ww * v[0];
+    wvb[g] = 0.5 * ww * v[1];
+    for (int k = 0; k < 3; k++) {
+        wva[(k + 1) * ng + g] = ww * (2.0 * v[2] * ga[k] + v[3] * gb[k]);
+        wvb[(k + 1) * ng + g] = ww * (2.0 * v[4] * gb[k] + v[3] * ga[k]);
+    }
+    wva[4 * ng + g] = 0.25 * ww * v[5];
+    wvb[4 * ng + g] = 0.25 * ww * v[6];
+}
+
+static int fill_xc_spec(XcSpec &X, const int32_t *kinds, const double *coefs, int nterms)
+{
+    if (nterms < 0 || nterms > 8) return fail("xc: at most 8 functional terms");
+    X = XcSpec{};
+    X.n = nterms;
+    for (int i = 0; i < nterms; i++) {
+        if (kinds[i] < XC_SLATER || kinds[i] > XC_M062X_C) return fail("xc: unknown functional id %d", kinds[i]);
+        X.kind[i] = kinds[i]; X.coef[i] = coefs[i];
+    }
+    return 0;
+}
+
+extern "C" int mi_xc_eval_mgga(const int32_t *kinds, const double *coefs, int nterms, const double *d_rho, const double *d_tau,
+                               const double *d_w, int64_t ng, double *d_exc, double *d_wv, void *stream)
+{
+    if (!d_rho || !d_tau || (d_wv && !d_w)) return fail("mi_xc_eval_mgga: null argument");
+    XcSpec X;
+    if (fill_xc_spec(X, kinds, coefs, nterms)) return -1;
+    if (ng <= 0) return 0;
+    hipLaunchKernelGGL(xc_eval_mgga_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, d_rho, d_tau, d_w, ng,
+                       d_exc, d_wv);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_xc_eval_mgga_spin(const int32_t *kinds, const double *coefs, int nterms, const double *d_rhoa, const double *d_rhob,
+                                    const double *d_taua, const double *d_taub, const double *d_w, int64_t ng, double *d_exc, double *d_wva,
+                                    double *d_wvb, void *stream)
+{
+    if (!d_rhoa || !d_rhob || !d_taua || !d_taub || !d_w || !d_wva || !d_wvb) return fail("mi_xc_eval_mgga_spin: null argument");
+    XcSpec X;
+    if (fill_xc_spec(X, kinds, coefs, nterms)) return -1;
+    if (ng <= 0) return 0;
+    hipLaunchKernelGGL(xc_eval_mgga_spin_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, d_rhoa, d_rhob,
+                       d_taua, d_taub, d_w, ng, d_exc, d_wva, d_wvb);
     HIPCHK(hipGetLastError());
     return 0;
 }

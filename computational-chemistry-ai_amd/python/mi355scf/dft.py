@@ -12,11 +12,13 @@ import torch
 from .grids import Grids, _grid_generation
 from .scf import RHF
 
-XC_IDS = {"slater": 1, "b88": 2, "vwn_rpa": 3, "vwn5": 4, "lyp": 5, "pbe_x": 6, "pbe_c": 7}
+XC_IDS = {"slater": 1, "b88": 2, "vwn_rpa": 3, "vwn5": 4, "lyp": 5, "pbe_x": 6, "pbe_c": 7,
+          "tpss_x": 8, "tpss_c": 9, "m062x_x": 10, "m062x_c": 11}
+MGGA_KINDS = ("tpss_x", "tpss_c", "m062x_x", "m062x_c")
 
 
 def parse_xc(name):
-    """-> (hyb, [(coef, kind_id)], is_gga)"""
+    """-> (hyb, [(coef, kind_id)], level): level 0 LDA, 1 GGA, 2 meta-GGA (truthy wherever AO gradients are needed)."""
     key = str(name).upper().replace("-", "").replace("_", "").replace(" ", "")
     table = {
         "HF": (1.0, []),
@@ -32,12 +34,17 @@ def parse_xc(name):
         "LDA,VWNRPA": (0.0, [(1.0, "slater"), (1.0, "vwn_rpa")]),
         "BLYP": (0.0, [(1.0, "b88"), (1.0, "lyp")]),
         "B88,LYP": (0.0, [(1.0, "b88"), (1.0, "lyp")]),
+        # meta-GGAs (templates/calculate_energy.py:263 `--method M06-2X`; templates/calculate_bde.py:105 default).  M06-2X: 54 %
+        # exact exchange; parameter tables entered from memory (csrc, "unverified-memory")
+        "TPSS": (0.0, [(1.0, "tpss_x"), (1.0, "tpss_c")]),
+        "TPSS,TPSS": (0.0, [(1.0, "tpss_x"), (1.0, "tpss_c")]),
+        "M062X": (0.54, [(1.0, "m062x_x"), (1.0, "m062x_c")]),
     }
     if key not in table:
         raise NotImplementedError(f"xc functional '{name}' is not implemented on the MI355X engine "
-                                  f"(have {sorted(table)}); meta-GGAs such as M06-2X are out of scope (SURVEY.md 8f-4)")
+                                  f"(have {sorted(table)})")
     hyb, terms = table[key]
-    gga = any(k not in ("slater", "vwn_rpa", "vwn5") for _c, k in terms)
+    gga = 2 if any(k in MGGA_KINDS for _c, k in terms) else int(any(k not in ("slater", "vwn_rpa", "vwn5") for _c, k in terms))
     return hyb, [(c, XC_IDS[k]) for c, k in terms], gga
 
 
@@ -103,11 +110,17 @@ class RKS(RHF):
                     cache.append(ao)
             C = dm @ ao[0]
             rho = eng.xc_rho(ao, C, deriv=1 if gga else 0)
-            e, wv = eng.xc_eval(terms, rho, w, gga)
+            if gga == 2:
+                e, wv = eng.xc_eval_mgga(terms, rho, eng.xc_tau(ao, dm), w)
+            else:
+                e, wv = eng.xc_eval(terms, rho, w, gga)
             tail[0] += torch.dot(w, rho[0])
             tail[1] += torch.dot(w, e)
             aow = eng.xc_aow(ao, wv, gga)
             eng.xc_vmat(ao[0], aow, vmat)      # vmat += ao0 . aow^T  (split-K FP64 MFMA kernel)
+            if gga == 2:                        # kinetic-energy-density term: sum_k ao_k . (w/4 vtau ao_k)^T
+                for k in (1, 2, 3):
+                    eng.xc_vmat(ao[k], wv[4] * ao[k], vmat)
         return hyb
 
     def _ao_cache_for(self, nao, npts, ncomp):

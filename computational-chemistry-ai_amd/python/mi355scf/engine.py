@@ -81,6 +81,8 @@ def lib():
         L.mi_xc_eval.argtypes = [ip, dp, ctypes.c_int, vp, vp, i64, ctypes.c_int, vp, vp, vp, vp, vp]
         L.mi_xc_eval_spin.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, i64, ctypes.c_int, vp, vp, vp, vp]
         L.mi_xc_aow.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
+        L.mi_xc_eval_mgga.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, i64, vp, vp, vp]
+        L.mi_xc_eval_mgga_spin.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.mi_xc_vmat.argtypes = [vp, vp, vp, i64, vp, vp]
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
@@ -335,6 +337,34 @@ class Engine:
                                 rho.data_ptr(), weights.data_ptr(), ng, int(gga), exc.data_ptr(), wv.data_ptr(),
                                 vr.data_ptr() if want_raw else None, vs.data_ptr() if want_raw else None, self._stream()))
         return (exc, wv, vr, vs) if want_raw else (exc, wv)
+
+    def xc_tau(self, ao, dm):
+        """tau[ng] = 1/2 sum_k sum_mu,nu D_mu,nu d_k phi_mu d_k phi_nu from AO gradients ao[1..3] (three D.ao_k GEMMs)."""
+        tau = None
+        for k in (1, 2, 3):
+            t = (ao[k] * (dm @ ao[k])).sum(dim=0)
+            tau = t if tau is None else tau + t
+        return 0.5 * tau
+
+    def xc_eval_mgga(self, terms, rho, tau, weights):
+        """meta-GGA: (exc[ng], wv[5][ng]); wv[4] = w/4 de/dtau."""
+        ng = rho.shape[-1]
+        kinds = np.array([k for _c, k in terms], dtype=np.int32)
+        coefs = np.array([c for c, _k in terms], dtype=np.float64)
+        exc, wv = self._new(ng), self._new(5, ng)
+        _check(lib().mi_xc_eval_mgga(kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dp(coefs), len(kinds), rho.data_ptr(),
+                                     tau.data_ptr(), weights.data_ptr(), ng, exc.data_ptr(), wv.data_ptr(), self._stream()))
+        return exc, wv
+
+    def xc_eval_mgga_spin(self, terms, rhoa, rhob, taua, taub, weights):
+        ng = rhoa.shape[-1]
+        kinds = np.array([k for _c, k in terms], dtype=np.int32)
+        coefs = np.array([c for c, _k in terms], dtype=np.float64)
+        exc, wva, wvb = self._new(ng), self._new(5, ng), self._new(5, ng)
+        _check(lib().mi_xc_eval_mgga_spin(kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _dp(coefs), len(kinds), rhoa.data_ptr(),
+                                          rhob.data_ptr(), taua.data_ptr(), taub.data_ptr(), weights.data_ptr(), ng, exc.data_ptr(),
+                                          wva.data_ptr(), wvb.data_ptr(), self._stream()))
+        return exc, wva, wvb
 
     def xc_aow(self, ao, wv, gga=True):
         ng = ao.shape[-1]

@@ -52,14 +52,20 @@ class Gradients:
             ao = eng.eval_ao(c, deriv=2 if gga else 1)
             C = dm @ ao[0]
             rho = eng.xc_rho(ao, C, deriv=1 if gga else 0)
-            _e, wv = eng.xc_eval(terms, rho, w, gga)
+            if gga == 2:
+                _e, wv = eng.xc_eval_mgga(terms, rho, eng.xc_tau(ao, dm), w)
+            else:
+                _e, wv = eng.xc_eval(terms, rho, w, gga)
             if gga:
+                Ck = [dm @ ao[1 + j] for j in range(3)]
                 T1 = 2.0 * wv[0] * C
                 for j in range(3):
-                    T1 += wv[1 + j] * (dm @ ao[1 + j])
+                    T1 += wv[1 + j] * Ck[j]
                 for k in range(3):
                     t2 = sum(wv[1 + j] * ao[pair[(min(j, k), max(j, k))]] for j in range(3))
                     fmu[:, k] += -2.0 * ((ao[1 + k] * T1).sum(dim=1) + (t2 * C).sum(dim=1))
+                    if gga == 2:   # d tau / d A_x = - sum_k (d_x d_k phi_mu) (D d_k phi)_mu ; wv[4] = w/4 de/dtau
+                        fmu[:, k] += -4.0 * sum((ao[pair[(min(j, k), max(j, k))]] * (wv[4] * Ck[j])).sum(dim=1) for j in range(3))
             else:
                 T1 = 2.0 * wv[0] * C
                 for k in range(3):
@@ -189,16 +195,22 @@ class UGradients(Gradients):
             ao = eng.eval_ao(c, deriv=2 if gga else 1)
             Cs = [dm[s_] @ ao[0] for s_ in range(2)]
             rho = [eng.xc_rho(ao, Cs[s_], deriv=1 if gga else 0) for s_ in range(2)]
-            _e, wva, wvb = eng.xc_eval_spin(terms, rho[0], rho[1], w, gga)
+            if gga == 2:
+                _e, wva, wvb = eng.xc_eval_mgga_spin(terms, rho[0], rho[1], eng.xc_tau(ao, dm[0]), eng.xc_tau(ao, dm[1]), w)
+            else:
+                _e, wva, wvb = eng.xc_eval_spin(terms, rho[0], rho[1], w, gga)
             for s_, wv in ((0, wva), (1, wvb)):
                 C = Cs[s_]
                 T1 = 2.0 * wv[0] * C
                 if gga:
+                    Ck = [dm[s_] @ ao[1 + j] for j in range(3)]
                     for j in range(3):
-                        T1 += wv[1 + j] * (dm[s_] @ ao[1 + j])
+                        T1 += wv[1 + j] * Ck[j]
                     for k in range(3):
                         t2 = sum(wv[1 + j] * ao[pair[(min(j, k), max(j, k))]] for j in range(3))
                         fmu[:, k] += -2.0 * ((ao[1 + k] * T1).sum(dim=1) + (t2 * C).sum(dim=1))
+                        if gga == 2:
+                            fmu[:, k] += -4.0 * sum((ao[pair[(min(j, k), max(j, k))]] * (wv[4] * Ck[j])).sum(dim=1) for j in range(3))
                 else:
                     for k in range(3):
                         fmu[:, k] += -2.0 * (ao[1 + k] * T1).sum(dim=1)

@@ -73,12 +73,18 @@ class UKS(UHF):
                 if cache is not None:
                     cache.append(ao)
             rho = [eng.xc_rho(ao, dm[s_] @ ao[0], deriv=1 if gga else 0) for s_ in range(2)]
-            e, wva, wvb = eng.xc_eval_spin(terms, rho[0], rho[1], w, gga)
+            if gga == 2:
+                e, wva, wvb = eng.xc_eval_mgga_spin(terms, rho[0], rho[1], eng.xc_tau(ao, dm[0]), eng.xc_tau(ao, dm[1]), w)
+            else:
+                e, wva, wvb = eng.xc_eval_spin(terms, rho[0], rho[1], w, gga)
             tail[0] += torch.dot(w, rho[0][0])
             tail[1] += torch.dot(w, rho[1][0])
             tail[2] += torch.dot(w, e)
             for s_, wv in ((0, wva), (1, wvb)):
                 eng.xc_vmat(ao[0], eng.xc_aow(ao, wv, gga), vmat[s_])
+                if gga == 2:
+                    for k in (1, 2, 3):
+                        eng.xc_vmat(ao[k], wv[4] * ao[k], vmat[s_])
         return hyb
 
     def _fock_pair(self, dm):

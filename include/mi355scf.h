@@ -230,6 +230,18 @@ int mi_grad_eri_spin(mi_ctx *ctx, const double *d_D, const double *d_Dspin, doub
 int mi_grad_eri_sharded(mi_ctx *ctx, const double *d_D, const double *d_Dspin, double hyb, double *d_grad, int rank,
                         int nranks, void *stream);
 
+/* meta-GGA evaluation (functional ids 8 TPSS exchange, 9 TPSS correlation, 10 M06-2X exchange, 11 M06-2X correlation; ids
+ * 1-7 may be mixed in): d_tau[ng] = 1/2 sum_i |grad phi_i|^2; d_wv[5][ng] as mi_xc_eval plus d_wv[4] = w/4 de/dtau (the caller
+ * adds sum_k ao_k^T (wv4 ao_k) to the unsymmetrised V_xc).  `--method M06-2X` at templates/calculate_energy.py:263;
+ * default functional of templates/calculate_bde.py:105.  Stands in for libxc MGGA_X/C_TPSS, HYB_MGGA_X_M06_2X, MGGA_C_M06_2X
+ * [MEM]; the M06-2X parameter tables are entered from memory (unverified). */
+int mi_xc_eval_mgga(const int32_t *kinds, const double *coefs, int nterms, const double *d_rho, const double *d_tau,
+                    const double *d_w, int64_t ng, double *d_exc, double *d_wv, void *stream);
+/* Spin-polarised form (UKS): per spin rho_s[4][ng], tau_s[ng] -> wv_s[5][ng]. */
+int mi_xc_eval_mgga_spin(const int32_t *kinds, const double *coefs, int nterms, const double *d_rhoa, const double *d_rhob,
+                         const double *d_taua, const double *d_taub, const double *d_w, int64_t ng, double *d_exc, double *d_wva,
+                         double *d_wvb, void *stream);
+
 /* d_vmat[nao][nao] += ao0 . aow^T over the grid block (split-K FP64 MFMA kernel; rocBLAS has no split-K for
  * this tiny-M,N / huge-K shape and runs it at < 1 TFLOP/s).  The caller symmetrises (Vxc = vmat + vmat^T). */
 int mi_xc_vmat(mi_ctx *ctx, const double *d_ao0, const double *d_aow, int64_t ng, double *d_vmat, void *stream);

@@ -548,3 +548,230 @@ def uks(mol, xc="B3LYP", level=3, dm0=None, conv_tol=1e-10, max_cycle=100, verbo
     dm = dens(F)
     F, e = fock(dm)
     return {"e_tot": e, "dm": dm, "nelec_grid": info["nelec"], "ngrids": len(weights)}
+
+
+# ---------------------------------------------------------------------------------------------
+# meta-GGA functionals (checker for `mi_xc_eval_mgga*`): numpy restatement of the published forms, complex-step safe.
+#   TPSS   : Tao, Perdew, Staroverov, Scuseria, PRL 91, 146401 (2003), eqs. 10 (exchange) and 11-14 (revPKZB correlation).
+#   M06-2X : Zhao, Truhlar, Theor. Chem. Acc. 120, 215 (2008).  PARAMETERS ENTERED FROM MEMORY ("unverified-memory"); what
+#            the tests pin are the uniform-gas sums (a0 + X = c0 + d0 = 1) and the one-electron limits.
+# ---------------------------------------------------------------------------------------------
+M062X_A = (4.600000e-01, -2.206052e-01, -9.431788e-02, 2.164494e+00, -2.556466e+00, -1.422133e+01,
+           1.555044e+01, 3.598078e+01, -2.722754e+01, -3.924093e+01, 1.522808e+01, 1.522227e+01)
+M062X_CSS = (3.097855e-01, -5.528642e+00, 1.347420e+01, -3.213623e+01, 2.846742e+01)
+M062X_CAB = (8.833596e-01, 3.357972e+01, -7.043548e+01, 4.978271e+01, -1.852891e+01)
+M062X_DSS = (6.902145e-01, 9.847204e-02, 2.214797e-01, -1.968264e-03, -6.775479e-03, 0.0)
+M062X_DAB = (1.166404e-01, -9.120847e-02, -6.726189e-02, 6.720580e-05, 8.448011e-04, 0.0)
+M062X_HYB = 0.54
+_CF6 = 0.6 * (6 * np.pi ** 2) ** (2.0 / 3)
+
+
+def _pw92_eps_spin(ra, rb):
+    r = ra + rb
+    rs = (3.0 / (4 * np.pi * r)) ** (1.0 / 3)
+    e0 = _pw92_g(rs, 0.031090690869654895, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294)
+    e1 = _pw92_g(rs, 0.015545345434827448, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517)
+    mac = _pw92_g(rs, 0.016886863940389627, 0.11125, 10.357, 3.6231, 0.88026, 0.49671)
+    z = _zeta(ra, rb)
+    fz, z4 = _fzeta(z), z ** 4
+    return e0 - mac * fz / _FPP0 * (1 - z4) + (e1 - e0) * fz * z4
+
+
+def _clip_hi(x, hi):
+    return np.where(np.real(x) > hi, hi + 0 * x, x)
+
+
+def _clip_lo(x, lo):
+    return np.where(np.real(x) < lo, lo + 0 * x, x)
+
+
+def _tpss_x_unpol(r, s, tau):
+    kappa, b, c, e, mu = 0.804, 0.40, 1.59096, 1.537, 0.21951
+    c3 = (3 * np.pi ** 2) ** (2.0 / 3)
+    p = s / (4 * c3 * r ** (8.0 / 3))
+    tw = s / (8 * r)
+    z = _clip_hi(tw / tau, 1.0)
+    alpha = _clip_lo((tau - tw) / (0.3 * c3 * r ** (5.0 / 3)), 0.0)
+    qb = 0.45 * (alpha - 1) / np.sqrt(1 + b * alpha * (alpha - 1)) + 2 * p / 3
+    x = ((10.0 / 81 + c * z * z / (1 + z * z) ** 2) * p + 146.0 / 2025 * qb * qb
+         - 73.0 / 405 * qb * np.sqrt(0.5 * (0.6 * z) ** 2 + 0.5 * p * p + 1e-300) + (10.0 / 81) ** 2 / kappa * p * p
+         + 2 * np.sqrt(e) * (10.0 / 81) * (0.6 * z) ** 2 + e * mu * p ** 3) / (1 + np.sqrt(e) * p) ** 2
+    ex = -0.75 * (3 / np.pi) ** (1.0 / 3) * r ** (4.0 / 3)
+    return ex * (1 + kappa - kappa / (1 + x / kappa))
+
+
+def _channel(ok, fn, *args):
+    """Evaluate `fn` only where the spin channel holds density (dummy arguments elsewhere), 0 otherwise."""
+    safe = [np.where(ok, a, 1.0 + 0 * a) for a in args]
+    return np.where(ok, fn(*safe), 0.0)
+
+
+def _tpss_x_spin(ra, rb, saa, sbb, ta, tb):
+    e = 0.0
+    for r_, s_, t_ in ((ra, saa, ta), (rb, sbb, tb)):
+        ok = (np.real(r_) > 1e-12) & (np.real(t_) > 1e-14)
+        e = e + _channel(ok, lambda r, s, t: 0.5 * _tpss_x_unpol(2 * r, 4 * s, 2 * t), r_, s_, t_)
+    return e
+
+
+def _tpss_c_spin(ra, rb, saa, sab, sbb, ta, tb):
+    d = 2.8
+    r, s, tau = ra + rb, saa + 2 * sab + sbb, ta + tb
+    z = _clip_hi(s / (8 * r) / tau, 1.0)
+    zeta = _zeta(ra, rb)
+    gz2 = _clip_lo(4 * (rb * rb * saa - 2 * ra * rb * sab + ra * ra * sbb) / r ** 4, 0.0)
+    xi2 = gz2 / (4 * (3 * np.pi ** 2 * r) ** (2.0 / 3))
+    C0 = 0.53 + 0.87 * zeta ** 2 + 0.50 * zeta ** 4 + 2.26 * zeta ** 6
+    C = C0 / (1 + xi2 * 0.5 * ((1 + zeta) ** (-4.0 / 3) + (1 - zeta) ** (-4.0 / 3))) ** 4
+    epbe = _pbe_c_spin(ra, rb, saa, sab, sbb) / r
+    ets = []
+    for r_, s_ in ((ra, saa), (rb, sbb)):
+        ok = np.real(r_) > 1e-12
+        one = _channel(ok, lambda rr, ss: _pbe_c_spin(rr, 0 * rr, ss, 0 * ss, 0 * ss) / rr, r_, s_)
+        ets.append(np.where(ok & (np.real(one) >= np.real(epbe)), one, epbe))
+    erev = epbe * (1 + C * z * z) - (1 + C) * z * z * (ra / r * ets[0] + rb / r * ets[1])
+    return r * erev * (1 + d * erev * z ** 3)
+
+
+def _m06_g(x2, cc, gamma):
+    u = gamma * x2 / (1 + gamma * x2)
+    return sum(c * u ** i for i, c in enumerate(cc))
+
+
+def _m06_h(x2, z, dc, alpha):
+    g = 1 + alpha * (x2 + z)
+    return dc[0] / g + (dc[1] * x2 + dc[2] * z) / g ** 2 + (dc[3] * x2 * x2 + dc[4] * x2 * z + dc[5] * z * z) / g ** 3
+
+
+def _m062x_x_spin(ra, rb, saa, sbb, ta, tb):
+    def chan(r, s, t):
+        tl = 0.3 * (6 * np.pi ** 2) ** (2.0 / 3) * r ** (5.0 / 3)
+        w = (tl / t - 1) / (tl / t + 1)
+        return 0.5 * _pbe_x(2 * r, 4 * s) * sum(a * w ** i for i, a in enumerate(M062X_A))
+    e = 0.0
+    for r_, s_, t_ in ((ra, saa, ta), (rb, sbb, tb)):
+        ok = (np.real(r_) > 1e-12) & (np.real(t_) > 1e-14)
+        e = e + _channel(ok, chan, r_, s_, t_)
+    return e
+
+
+def _m062x_c_spin(ra, rb, saa, sbb, ta, tb):
+    oka = (np.real(ra) > 1e-12) & (np.real(ta) > 1e-14)
+    okb = (np.real(rb) > 1e-12) & (np.real(tb) > 1e-14)
+    sa = [np.where(oka, a, 1.0 + 0 * a) for a in (ra, saa, ta)]
+    sb = [np.where(okb, a, 1.0 + 0 * a) for a in (rb, sbb, tb)]
+    out = 0.0
+    xs, zs, ess = [], [], []
+    for ok, (r, s, t) in ((oka, sa), (okb, sb)):
+        x2 = s / r ** (8.0 / 3)
+        z = 2 * t / r ** (5.0 / 3) - _CF6
+        e_ss = r * _pw92_eps_spin(r, 0 * r)
+        D = _clip_lo(1 - x2 / (4 * (z + _CF6)), 0.0)
+        out = out + np.where(ok, e_ss * (_m06_g(x2, M062X_CSS, 0.06) + _m06_h(x2, z, M062X_DSS, 0.00515088)) * D, 0.0)
+        xs.append(x2); zs.append(z); ess.append(e_ss)
+    both = oka & okb
+    eab = (sa[0] + sb[0]) * _pw92_eps_spin(sa[0], sb[0]) - ess[0] - ess[1]
+    out = out + np.where(both, eab * (_m06_g(xs[0] + xs[1], M062X_CAB, 0.0031) + _m06_h(xs[0] + xs[1], zs[0] + zs[1], M062X_DAB, 0.00304966)), 0.0)
+    return out
+
+
+MGGA_TERMS = {"tpss_x": lambda ra, rb, saa, sab, sbb, ta, tb: _tpss_x_spin(ra, rb, saa, sbb, ta, tb),
+              "tpss_c": _tpss_c_spin,
+              "m062x_x": lambda ra, rb, saa, sab, sbb, ta, tb: _m062x_x_spin(ra, rb, saa, sbb, ta, tb),
+              "m062x_c": lambda ra, rb, saa, sab, sbb, ta, tb: _m062x_c_spin(ra, rb, saa, sbb, ta, tb)}
+
+
+def parse_xc_mgga(name):
+    key = str(name).upper().replace("-", "").replace("_", "").replace(" ", "")
+    if key in ("TPSS", "TPSS,TPSS"):
+        return 0.0, [(1.0, "tpss_x"), (1.0, "tpss_c")]
+    if key == "M062X":
+        return M062X_HYB, [(1.0, "m062x_x"), (1.0, "m062x_c")]
+    return None
+
+
+def energy_density_mgga_spin(terms, ra, rb, saa, sab, sbb, ta, tb):
+    e = 0.0
+    for coef, kind in terms:
+        if kind in MGGA_TERMS:
+            e = e + coef * MGGA_TERMS[kind](ra, rb, saa, sab, sbb, ta, tb)
+        else:
+            e = e + energy_density_spin([(coef, kind)], ra, rb, saa, sab, sbb)
+    return e
+
+
+def eval_xc_mgga(terms, rho, sigma, tau):
+    """closed shell: (e, de/drho, de/dsigma, de/dtau) by complex steps."""
+    h = 1e-30
+
+    def f(r, s, t):
+        return energy_density_mgga_spin(terms, r / 2, r / 2, s / 4, s / 4, s / 4, t / 2, t / 2)
+    e = np.real(f(rho + 0j, sigma + 0j, tau + 0j))
+    vr = np.imag(f(rho + 1j * h, sigma + 0j, tau + 0j)) / h
+    vs = np.imag(f(rho + 0j, sigma + 1j * h, tau + 0j)) / h
+    vt = np.imag(f(rho + 0j, sigma + 0j, tau + 1j * h)) / h
+    return e, vr, vs, vt
+
+
+def eval_xc_mgga_spin(terms, ra, rb, saa, sab, sbb, ta, tb):
+    """(e, [7 partial derivatives]) by complex steps."""
+    h = 1e-30
+    args = [np.asarray(a, dtype=complex) for a in (ra, rb, saa, sab, sbb, ta, tb)]
+    e = np.real(energy_density_mgga_spin(terms, *args))
+    ds = []
+    for i in range(7):
+        a2 = [a + (1j * h if j == i else 0) for j, a in enumerate(args)]
+        ds.append(np.imag(energy_density_mgga_spin(terms, *a2)) / h)
+    return e, ds
+
+
+def nr_rks_mgga(mol, coords, weights, xc, dm, block=20000, rho_cut=1e-10):
+    hyb, terms = parse_xc_mgga(xc)
+    nao = mol.nao
+    nelec = exc = 0.0
+    vmat = np.zeros((nao, nao))
+    for p0 in range(0, len(coords), block):
+        c, w = coords[p0:p0 + block], weights[p0:p0 + block]
+        ao = eval_ao(mol, c, 1)
+        c0 = ao[0] @ dm
+        ck = [ao[1 + k] @ dm for k in range(3)]
+        rho = np.einsum("gi,gi->g", ao[0], c0)
+        grad = np.array([2 * np.einsum("gi,gi->g", ao[1 + k], c0) for k in range(3)])
+        tau = 0.5 * sum(np.einsum("gi,gi->g", ao[1 + k], ck[k]) for k in range(3))
+        sigma = (grad * grad).sum(axis=0)
+        ok = rho > rho_cut
+        e, vr, vs, vt = eval_xc_mgga(terms, np.where(ok, rho, 1.0), np.where(ok, sigma, 0.0), np.where(ok, tau, 1.0))
+        e, vr, vs, vt = (np.where(ok, x, 0) for x in (e, vr, vs, vt))
+        nelec += float(w @ rho)
+        exc += float(w @ e)
+        aow = ao[0] * (0.5 * w * vr)[:, None]
+        for k in range(3):
+            aow += ao[1 + k] * (2 * w * vs * grad[k])[:, None]
+        vmat += ao[0].T @ aow
+        for k in range(3):
+            vmat += ao[1 + k].T @ (ao[1 + k] * (0.25 * w * vt)[:, None])
+    return nelec, exc, vmat + vmat.T, hyb
+
+
+def rks_mgga(mol, xc="TPSS", level=3, dm0=None, conv_tol=1e-9, max_cycle=50, verbose=False):
+    """Closed-shell meta-GGA Kohn-Sham on the oracle integrals (no small-density grid pruning: compare with
+    `mf.small_rho_cutoff = 0`)."""
+    coords, weights = build_grids(mol, level)
+    o = orc.Oracle(mol)
+    info = {}
+
+    def veff(dm):
+        n, exc, vxc, hyb = nr_rks_mgga(mol, coords, weights, xc, dm)
+        J, K = o.jk(dm)
+        info["nelec"] = n
+        v = J + vxc
+        e2 = 0.5 * float(np.sum(dm * J)) + exc
+        if hyb:
+            v = v - 0.5 * hyb * K
+            e2 -= 0.25 * hyb * float(np.sum(dm * K))
+        return v, e2
+
+    r = orc.rhf(mol, dm0=dm0, conv_tol=conv_tol, max_cycle=max_cycle, veff_fn=veff, verbose=verbose, oracle=o)
+    r["nelec_grid"] = info.get("nelec")
+    r["ngrids"] = len(weights)
+    return r

@@ -43,9 +43,38 @@ def test_xc_name_parsing():
     from mi355scf.dft import parse_xc
     hyb, terms, gga = parse_xc("B3LYP")
     assert hyb == 0.2 and gga and abs(sum(c for c, _ in terms) - (0.08 + 0.72 + 0.19 + 0.81)) < 1e-15
-    assert parse_xc("pbe")[0] == 0.0 and parse_xc("PBE0")[0] == 0.25 and parse_xc("lda,vwn")[2] is False
+    assert parse_xc("pbe")[0] == 0.0 and parse_xc("PBE0")[0] == 0.25 and not parse_xc("lda,vwn")[2]
+    hyb, terms, level = parse_xc("M06-2X")          # templates/calculate_energy.py:263; calculate_bde.py:105 default
+    assert hyb == 0.54 and level == 2 and parse_xc("TPSS")[2] == 2 and parse_xc("B3LYP")[2] == 1
     with pytest.raises(NotImplementedError):
-        parse_xc("M06-2X")
+        parse_xc("SCAN")
+
+
+def test_oracle_meta_gga_limits():
+    """The numpy restatement of TPSS / M06-2X (oracle/dft.py; the M06-2X tables are unverified-memory) obeys what the papers
+    guarantee: both reduce to LSDA (+ their share of exact exchange) for the uniform gas; their correlation vanishes for any
+    one-electron density; TPSS exchange gives the exact -0.3125 Ha for the hydrogen atom."""
+    from oracle import dft as od
+    r = np.array([0.05, 0.3, 1.0, 5.0])
+    tu = 0.3 * (3 * np.pi ** 2) ** (2.0 / 3) * r ** (5.0 / 3)
+    for name in ("TPSS", "M06-2X"):
+        hyb, terms = od.parse_xc_mgga(name)
+        e = od.eval_xc_mgga(terms, r, 0 * r, tu)[0]
+        lsda = (1 - hyb) * (-0.75 * (3 / np.pi) ** (1.0 / 3) * r ** (4.0 / 3)) + r * od._pw92_eps_spin(r / 2, r / 2)
+        assert np.abs(e / lsda - 1).max() < 1e-12
+    assert abs(od.M062X_A[0] + od.M062X_HYB - 1) < 1e-12 and abs(od.M062X_CSS[0] + od.M062X_DSS[0] - 1) < 1e-7 \
+        and abs(od.M062X_CAB[0] + od.M062X_DAB[0] - 1) < 1e-7
+    rr = np.linspace(1e-4, 30, 200001)
+    dr = rr[1] - rr[0]
+    rho = np.exp(-2 * rr) / np.pi
+    sig = (2 * rho) ** 2
+    tau = sig / (8 * rho)                              # one electron: tau = tau_W
+    vol = 4 * np.pi * rr ** 2 * dr
+    assert abs(np.sum(vol * od._tpss_x_spin(rho, 0 * rho, sig, 0 * sig, tau, 0 * tau)) + 0.3125) < 2e-6
+    assert abs(np.sum(vol * od._tpss_c_spin(rho, 0 * rho, sig, 0 * sig, 0 * sig, tau, 0 * tau))) < 1e-12
+    assert abs(np.sum(vol * od._m062x_c_spin(rho, 0 * rho, sig, 0 * sig, tau, 0 * tau))) < 1e-12
+    ex = np.sum(vol * od._m062x_x_spin(rho, 0 * rho, sig, 0 * sig, tau, 0 * tau)) + od.M062X_HYB * (-0.3125)
+    assert -0.3125 - 0.01 < ex < -0.3125 + 0.01
 
 
 def test_grid_tables():
