@@ -4058,6 +4058,337 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
     }
 }
 
+// =================================================================================================
+// Derivative ERIs contracted with the two-particle density, LOW angular classes: one THREAD per (canonical quartet, role
+// permutation), everything in registers (the gradient counterpart of eri_tpq_kernel; round 1 spent 1.6 of the 1.9 s of the
+// ibuprofen/def2-TZVP gradient in the wave-per-quartet path of these classes).
+//   d/dA_x (a b| = 2 alpha (a+1_x b| - a_x (a-1_x b|: the primitive loop accumulates the [e0|f0] blocks of the (L1+1) shell
+//   (coefficients 2 alpha c, folded into the "plus" pair record) and of the (L1-1) shell side by side (same roots, same 2-D
+//   recurrence tables); the ket is transformed first, then for each ket component the bra goes HRR -> derivative -> cart->sph
+//   and is contracted at once with G = D_ab D_cd - hyb/4 (D_ac D_bd + D_ad D_bc) (+ spin term): no derivative block is stored.
+// L1 = differentiated shell, L2 = its partner (either order), (LC >= LD) the other pair.
+// =================================================================================================
+struct TpqGradArgs {
+    const PairRec *dplus, *dminus, *ket;
+    const double *prim;
+    const int64_t *prefix;
+    int nbra;
+    int64_t t0, ntask;
+    int swap, same_class;
+    const double *c2s;
+    int c2s_off[LMAX + 2];
+    RysDev rys;
+    const double *shell_xyz;
+    const double *D, *Dm;     // padded total / spin density
+    int ld;
+    double hyb;
+    const int *shell_atom;
+    double *grad;             // GRAD_COPIES private copies of [natm3]
+    int natm3, inv_from_second;
+    const double *q_bra, *q_ket, *dmax;
+    int nbas_d;
+    double dtol;
+};
+
+template <int L1, int L2, int LC, int LD>
+__global__ __launch_bounds__(TPQ_BLOCK) void eri_tpq_grad_kernel(TpqGradArgs A)
+{
+    constexpr bool HASM = L1 > 0;
+    constexpr int LP = L1 + 1, LM = HASM ? L1 - 1 : 0;
+    constexpr int NR = (LP + L2 + LC + LD) / 2 + 1;
+    constexpr int NMAX = LP + L2, MMAX = LC + LD;
+    constexpr int NEP = c_ne(LP, L2), NEM = HASM ? c_ne(LM, L2) : 0, NF = c_ne(LC, LD);
+    constexpr int NS1 = 2 * L1 + 1, NS2 = 2 * L2 + 1, NSC = 2 * LC + 1, NSD = 2 * LD + 1, NSCD = NSC * NSD;
+    constexpr int NK1 = c_ncart(L1), NK2 = c_ncart(L2), NCP = c_ncart(LP), NCM = HASM ? c_ncart(LM) : 1;
+    extern __shared__ double cheb[];
+    const int nint = A.rys.nint[NR];
+    {
+        const int ntab = nint * 2 * NR * (RYS_DEG + 1);
+        const double *src = A.rys.cheb + A.rys.off[NR];
+        for (int q = threadIdx.x; q < ntab; q += TPQ_BLOCK) cheb[q] = src[q];
+    }
+    __syncthreads();
+    const int64_t tl = (int64_t)blockIdx.x * TPQ_BLOCK + threadIdx.x;
+    bool live = tl < A.ntask;
+    int ib = 0, ik = 0;
+    if (live) find_task(A.prefix, A.nbra, A.t0 + tl, ib, ik);
+    const bool same_pair = A.same_class && ib == ik;
+    if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
+    const PairRec dp = A.dplus[ib], cd = A.ket[ik];
+    if (live && A.dmax && A.q_bra[ib] * A.q_ket[ik] * quartet_density_bound(A.dmax, A.nbas_d, dp.sh_i, dp.sh_j, cd.sh_i, cd.sh_j, A.hyb) < A.dtol)
+        live = false;
+    double force[3] = {0.0, 0.0, 0.0};
+    if (live) {
+        int mprim_off = 0;
+        if (HASM) mprim_off = A.dminus[ib].prim_off;
+        double accp[NEP * NF], accm[(HASM ? NEM : 1) * NF];
+#pragma unroll
+        for (int q = 0; q < NEP * NF; q++) accp[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < (HASM ? NEM : 1) * NF; q++) accm[q] = 0.0;
+        for (int ip = 0; ip < dp.nprim; ip++) {
+            const double *b = A.prim + (size_t)(dp.prim_off + ip) * 8;
+            const double p = b[0], Px = b[1], Py = b[2], Pz = b[3], Kp = b[7];
+            const double Km = HASM ? A.prim[(size_t)(mprim_off + ip) * 8 + 7] : 0.0;
+            const double PA[3] = {b[4], b[5], b[6]};
+            for (int jp = 0; jp < cd.nprim; jp++) {
+                const double *kk = A.prim + (size_t)(cd.prim_off + jp) * 8;
+                const double q = kk[0];
+                const double PQ[3] = {Px - kk[1], Py - kk[2], Pz - kk[3]};
+                const double QC[3] = {kk[4], kk[5], kk[6]};
+                const double pq1 = 1.0 / (p + q);
+                const double x = p * q * pq1 * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
+                const double pref = kk[7] * 34.986836655249725 /* 2 pi^2.5 */ * pq1 * sqrt(p + q) / (p * q);
+                double u[NR], w[NR];
+                if (x < nint * RYS_H) {
+                    int iv = (int)(x * (1.0 / RYS_H));
+                    if (iv >= nint) iv = nint - 1;
+                    const double sx = (x - (iv * RYS_H + 0.5 * RYS_H)) * (2.0 / RYS_H), s2 = 2.0 * sx;
+                    const double *cb = cheb + (size_t)iv * 2 * NR * (RYS_DEG + 1);
+#pragma unroll
+                    for (int f = 0; f < 2 * NR; f++) {
+                        const double *cc = cb + f * (RYS_DEG + 1);
+                        double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+                        for (int kq = RYS_DEG; kq >= 1; kq--) {
+                            double tq = s2 * b1 - b2 + cc[kq];
+                            b2 = b1;
+                            b1 = tq;
+                        }
+                        const double val = sx * b1 - b2 + cc[0];
+                        if (f < NR) u[f] = val; else w[f - NR] = val;
+                    }
+                } else {
+                    const double rx = 1.0 / x, rsx = rsqrt(x);
+#pragma unroll
+                    for (int f = 0; f < NR; f++) { u[f] = A.rys.herm_r[NR * RYS_NMAX + f] * rx; w[f] = A.rys.herm_w[NR * RYS_NMAX + f] * rsx; }
+                }
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const double ur = u[r];
+                    const double b00 = 0.5 * ur * pq1, b10 = 0.5 / p * (1.0 - ur * q * pq1), b01 = 0.5 / q * (1.0 - ur * p * pq1);
+                    double T[3][NMAX + 1][MMAX + 1];
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        const double c00 = PA[d] - ur * q * pq1 * PQ[d], c01 = QC[d] + ur * p * pq1 * PQ[d];
+                        T[d][0][0] = d == 2 ? w[r] * pref : 1.0;
+#pragma unroll
+                        for (int n = 0; n < NMAX; n++) T[d][n + 1][0] = c00 * T[d][n][0] + (n > 0 ? n * b10 * T[d][n - 1][0] : 0.0);
+#pragma unroll
+                        for (int m = 0; m < MMAX; m++)
+#pragma unroll
+                            for (int n = 0; n <= NMAX; n++) {
+                                double v = c01 * T[d][n][m];
+                                if (m > 0) v = fma(m * b01, T[d][n][m - 1], v);
+                                if (n > 0) v = fma(n * b00, T[d][n - 1][m], v);
+                                T[d][n][m + 1] = v;
+                            }
+                    }
+#pragma unroll
+                    for (int df = LC; df <= LC + LD; df++)
+#pragma unroll
+                        for (int fx = df; fx >= 0; fx--)
+#pragma unroll
+                            for (int fy = df - fx; fy >= 0; fy--) {
+                                const int fz = df - fx - fy, jf = c_eoff(LC, df) + c_cidx(df, fx, fy);
+                                // plus block: degrees LP .. LP + L2
+#pragma unroll
+                                for (int de = LP; de <= LP + L2; de++)
+#pragma unroll
+                                    for (int ex = de; ex >= 0; ex--)
+#pragma unroll
+                                        for (int ey = de - ex; ey >= 0; ey--) {
+                                            const int ez = de - ex - ey, ie = c_eoff(LP, de) + c_cidx(de, ex, ey);
+                                            accp[ie * NF + jf] = fma(Kp * T[0][ex][fx] * T[1][ey][fy], T[2][ez][fz], accp[ie * NF + jf]);
+                                        }
+                                if (HASM) {
+#pragma unroll
+                                    for (int de = LM; de <= LM + L2; de++)
+#pragma unroll
+                                        for (int ex = de; ex >= 0; ex--)
+#pragma unroll
+                                            for (int ey = de - ex; ey >= 0; ey--) {
+                                                const int ez = de - ex - ey, ie = c_eoff(LM, de) + c_cidx(de, ex, ey);
+                                                accm[ie * NF + jf] = fma(Km * T[0][ex][fx] * T[1][ey][fy], T[2][ez][fz], accm[ie * NF + jf]);
+                                            }
+                                }
+                            }
+                }
+            }
+        }
+        // ---- ket: HRR + cart->sph on the f index of both blocks
+        const MI_CONST_AS double *c2s = as_const(A.c2s);
+        double ABv[3], CDv[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            ABv[d] = A.shell_xyz[3 * dp.sh_i + d] - A.shell_xyz[3 * dp.sh_j + d];
+            CDv[d] = A.shell_xyz[3 * cd.sh_i + d] - A.shell_xyz[3 * cd.sh_j + d];
+        }
+        double Ep[NEP * NSCD], Em[(HASM ? NEM : 1) * NSCD];
+        tpq_pair_transform<LC, LD, NEP, 1, NF, 1, NSCD>(accp, Ep, CDv, c2s + A.c2s_off[LC], c2s + A.c2s_off[LD]);
+        if (HASM) tpq_pair_transform<LC, LD, NEM, 1, NF, 1, NSCD>(accm, Em, CDv, c2s + A.c2s_off[LC], c2s + A.c2s_off[LD]);
+        // ---- bra per ket component: HRR (closed form) -> derivative -> cart->sph -> contraction with G
+        double pw[3][L2 + 1];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            pw[d][0] = 1.0;
+#pragma unroll
+            for (int q = 1; q <= L2; q++) pw[d][q] = pw[d][q - 1] * ABv[d];
+        }
+        const MI_CONST_AS double *c1 = c2s + A.c2s_off[L1], *c2 = c2s + A.c2s_off[L2];
+        const double *D = A.D;
+        const int ld = A.ld;
+#pragma unroll
+        for (int col = 0; col < NSCD; col++) {
+            const int sc = col / NSD, sd = col - sc * NSD;
+            // (a' b| for the plus (a' of degree LP) and minus (degree LM) shells
+            double gp[NCP * NK2], gm[NCM * NK2];
+#pragma unroll
+            for (int pass = 0; pass < (HASM ? 2 : 1); pass++) {
+                const int LX = pass == 0 ? LP : LM;
+#pragma unroll
+                for (int ax = LX; ax >= 0; ax--)
+#pragma unroll
+                    for (int ay = LX - ax; ay >= 0; ay--) {
+                        const int ia = c_cidx(LX, ax, ay);
+#pragma unroll
+                        for (int bx = L2; bx >= 0; bx--)
+#pragma unroll
+                            for (int by = L2 - bx; by >= 0; by--) {
+                                const int bz = L2 - bx - by, ibb = c_cidx(L2, bx, by);
+                                double v = 0.0;
+#pragma unroll
+                                for (int ix = 0; ix <= bx; ix++)
+#pragma unroll
+                                    for (int iy = 0; iy <= by; iy++)
+#pragma unroll
+                                        for (int iz = 0; iz <= bz; iz++) {
+                                            const int deg = LX + ix + iy + iz;
+                                            const int e = c_eoff(LX, deg) + c_cidx(deg, ax + ix, ay + iy);
+                                            const double cf = (double)(c_binom(bx, ix) * c_binom(by, iy) * c_binom(bz, iz));
+                                            const double src = pass == 0 ? Ep[e * NSCD + col] : Em[(HASM ? e : 0) * NSCD + col];
+                                            v = fma(cf * pw[0][bx - ix] * pw[1][by - iy] * pw[2][bz - iz], src, v);
+                                        }
+                                if (pass == 0) gp[ia * NK2 + ibb] = v; else gm[ia * NK2 + ibb] = v;
+                            }
+                    }
+            }
+            // density factor of this ket component for every bra component
+            const int k = cd.ao_i + sc, l = cd.ao_j + sd;
+            double Gd[NS1 * NS2];
+#pragma unroll
+            for (int sa = 0; sa < NS1; sa++)
+#pragma unroll
+                for (int sb = 0; sb < NS2; sb++) {
+                    const int i = dp.ao_i + sa, j = dp.ao_j + sb;
+                    double ex = D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k];
+                    if (A.Dm) ex += A.Dm[(size_t)i * ld + k] * A.Dm[(size_t)j * ld + l] + A.Dm[(size_t)i * ld + l] * A.Dm[(size_t)j * ld + k];
+                    Gd[sa * NS2 + sb] = D[(size_t)i * ld + j] * D[(size_t)k * ld + l] - 0.25 * A.hyb * ex;
+                }
+            // Gc[a][b] = sum_{sa,sb} c1[a][sa] c2[b][sb] Gd[sa][sb]   (density back-transformed to cartesians: 3x fewer products)
+            double h2[NS1 * NK2];
+#pragma unroll
+            for (int sa = 0; sa < NS1; sa++)
+#pragma unroll
+                for (int bq = 0; bq < NK2; bq++) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int sb = 0; sb < NS2; sb++) v = fma(c2[bq * NS2 + sb], Gd[sa * NS2 + sb], v);
+                    h2[sa * NK2 + bq] = v;
+                }
+            double Gc[NK1 * NK2];
+#pragma unroll
+            for (int a = 0; a < NK1; a++)
+#pragma unroll
+                for (int bq = 0; bq < NK2; bq++) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int sa = 0; sa < NS1; sa++) v = fma(c1[a * NS1 + sa], h2[sa * NK2 + bq], v);
+                    Gc[a * NK2 + bq] = v;
+                }
+            // derivative: d_x (a b| = (a+1_x b|_plus - a_x (a-1_x b|_minus
+#pragma unroll
+            for (int ax = L1; ax >= 0; ax--)
+#pragma unroll
+                for (int ay = L1 - ax; ay >= 0; ay--) {
+                    const int az = L1 - ax - ay, ia = c_cidx(L1, ax, ay);
+                    const int apow[3] = {ax, ay, az};
+#pragma unroll
+                    for (int xdir = 0; xdir < 3; xdir++) {
+                        const int px = ax + (xdir == 0), py = ay + (xdir == 1);
+                        const int ipl = c_cidx(LP, px, py);
+#pragma unroll
+                        for (int bq = 0; bq < NK2; bq++) {
+                            double dv = gp[ipl * NK2 + bq];
+                            if (HASM && apow[xdir] > 0) {
+                                const int mx = ax - (xdir == 0), my = ay - (xdir == 1);
+                                dv -= apow[xdir] * gm[c_cidx(LM, mx, my) * NK2 + bq];
+                            }
+                            force[xdir] = fma(dv, Gc[ia * NK2 + bq], force[xdir]);
+                        }
+                    }
+                }
+        }
+        double wq = 4.0;
+        if (dp.sh_i == dp.sh_j) wq *= 0.5;
+        if (cd.sh_i == cd.sh_j) wq *= 0.5;
+        if (same_pair) wq *= 0.5;
+#pragma unroll
+        for (int xdir = 0; xdir < 3; xdir++) force[xdir] *= wq;
+    }
+    // ---- forces: +f on the atom of the differentiated shell, -f on the atom of the skipped permutation.  Lanes of a wave
+    // mostly share both atoms (consecutive tasks share the bra pair): reduce over the wave first when they all do.
+    const int a1 = A.shell_atom[dp.sh_i], a2 = A.shell_atom[A.inv_from_second ? dp.sh_j : cd.sh_i];
+    const int lane = threadIdx.x & 63;
+    const bool uniform = __all(a1 == __shfl(a1, 0) && a2 == __shfl(a2, 0));
+    double *gc = A.grad + (size_t)(blockIdx.x & (GRAD_COPIES - 1)) * A.natm3;
+    if (uniform) {
+#pragma unroll
+        for (int xdir = 0; xdir < 3; xdir++) {
+            double v = force[xdir];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && v != 0.0) { atomicAdd(&gc[a1 * 3 + xdir], v); atomicAdd(&gc[a2 * 3 + xdir], -v); }
+        }
+    } else if (live) {
+#pragma unroll
+        for (int xdir = 0; xdir < 3; xdir++) { atomicAdd(&gc[a1 * 3 + xdir], force[xdir]); atomicAdd(&gc[a2 * 3 + xdir], -force[xdir]); }
+    }
+}
+
+template <int L1, int L2, int LC, int LD>
+static int launch_eri_tpq_grad_t(const TpqGradArgs &Q, hipStream_t st)
+{
+    constexpr int NR = (L1 + 1 + L2 + LC + LD) / 2 + 1;
+    const size_t shm = sizeof(double) * (size_t)RYS_NINT_H[NR] * 2 * NR * (RYS_DEG + 1);
+    if (Q.ntask <= 0) return 1;   // nothing in this rank's share of the class (the class is still "handled")
+    hipLaunchKernelGGL((eri_tpq_grad_kernel<L1, L2, LC, LD>), dim3((unsigned)((Q.ntask + TPQ_BLOCK - 1) / TPQ_BLOCK)), dim3(TPQ_BLOCK), shm, st, Q);
+    if (hipGetLastError() != hipSuccess) return fail("eri_tpq_grad_kernel launch failed");
+    return 1;
+}
+
+// returns 1 if the class (l1 = differentiated shell, l2 = partner | lc >= ld) has a thread-per-quartet kernel, 0 otherwise
+static int launch_eri_tpq_grad(int l1, int l2, int lc, int ld, const TpqGradArgs &Q, hipStream_t st)
+{
+    const int key = ((l1 * 4 + l2) * 4 + lc) * 4 + ld;
+#define TPQG_CASE(a, b, c_, d) case (((a) * 4 + (b)) * 4 + (c_)) * 4 + (d): return launch_eri_tpq_grad_t<a, b, c_, d>(Q, st)
+    switch (key) {
+        // other pair (ss)
+        TPQG_CASE(0, 0, 0, 0); TPQG_CASE(1, 0, 0, 0); TPQG_CASE(0, 1, 0, 0); TPQG_CASE(1, 1, 0, 0); TPQG_CASE(2, 0, 0, 0);
+        TPQG_CASE(2, 1, 0, 0); TPQG_CASE(1, 2, 0, 0); TPQG_CASE(3, 0, 0, 0); TPQG_CASE(2, 2, 0, 0);
+        TPQG_CASE(3, 1, 0, 0);   // (sd|ss), (sf|ss), (pf|ss): the compiler leaves their index arrays in scratch -> wave-per-quartet path
+        // other pair (ps)
+        TPQG_CASE(0, 0, 1, 0); TPQG_CASE(1, 0, 1, 0); TPQG_CASE(0, 1, 1, 0); TPQG_CASE(1, 1, 1, 0); TPQG_CASE(2, 0, 1, 0); TPQG_CASE(0, 2, 1, 0);
+        TPQG_CASE(3, 0, 1, 0);
+        // other pair (pp), (ds), (fs), (dp): (NEP + NEM) * NF accumulators <= ~64
+        TPQG_CASE(0, 0, 1, 1); TPQG_CASE(1, 0, 1, 1);
+        TPQG_CASE(0, 0, 2, 0); TPQG_CASE(1, 0, 2, 0); TPQG_CASE(0, 1, 2, 0);
+        TPQG_CASE(0, 0, 3, 0);
+        TPQG_CASE(0, 0, 2, 1);
+    default: return 0;
+    }
+#undef TPQG_CASE
+}
+
 // max |D| over the AO block of every shell pair (density-weighted screening of the derivative quartets)
 __global__ void shell_dmax_kernel(const double *D, const double *Dm, int ld, const int *sh_ao, const int *sh_n, int nbas, double *out)
 {
@@ -4179,6 +4510,33 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 PairClass &Oc = swap ? B : Kc;   // class of the other pair (plain ket)
                 const int l1 = orient == 0 ? Dc.la : Dc.lb, l2 = orient == 0 ? Dc.lb : Dc.la;
                 const int lc = Oc.la, ldd = Oc.lb;
+                if (c->opt_eri_tpq) {   // low classes: thread per (quartet, permutation), fused (eri_tpq_grad_kernel)
+                    TpqGradArgs Q{};
+                    Q.dplus = Dc.d_g_recs[orient][0]; Q.dminus = l1 >= 1 ? Dc.d_g_recs[orient][1] : nullptr; Q.ket = Oc.d_recs;
+                    Q.prim = c->d_prim; Q.prefix = d_prefix; Q.nbra = (int)B.recs.size();
+                    // this rank's contiguous share of the task list
+                    const int64_t lo_t = ntask * rank / nranks, hi_t = ntask * (rank + 1) / nranks;
+                    Q.t0 = lo_t; Q.ntask = hi_t - lo_t;
+                    Q.swap = swap ? 1 : 0; Q.same_class = (bc == kc);
+                    Q.c2s = c->d_c2s;
+                    for (int q = 0; q <= LMAX + 1; q++) Q.c2s_off[q] = c->c2s_off[q];
+                    Q.rys = c->rys; Q.shell_xyz = c->d_shell_xyz; Q.D = c->d_Dpad; Q.Dm = d_Mpad; Q.ld = c->ldp; Q.hyb = hyb;
+                    Q.shell_atom = d_shell_atom; Q.grad = d_gcopies; Q.natm3 = natm3; Q.inv_from_second = swap ? 0 : 1;
+                    Q.q_bra = Dc.d_q; Q.q_ket = Oc.d_q; Q.dmax = d_dmax; Q.nbas_d = c->nbas; Q.dtol = c->opt_grad_dtol;
+                    const bool dbg1 = getenv("MI355_DEBUG") != nullptr;
+                    auto tq0 = std::chrono::steady_clock::now();
+                    if (dbg1) hipStreamSynchronize(st);
+                    const int used = launch_eri_tpq_grad(l1, l2, lc, ldd, Q, st);
+                    if (used < 0) return -1;
+                    if (used) {
+                        if (dbg1) {
+                            hipStreamSynchronize(st);
+                            fprintf(stderr, "[mi355] grad class (%d%d|%d%d) perm %d: %ld quartets, %.3f s (thread per quartet)\n", l1, l2, lc, ldd, perm,
+                                    (long)ntask, std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count());
+                        }
+                        continue;
+                    }
+                }
                 EriArgs Ep{}, Em{};
                 setup_eri_dims(Ep, l1 + 1, l2, lc, ldd);
                 const bool has_m = l1 >= 1;
