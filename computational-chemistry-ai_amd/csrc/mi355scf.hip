@@ -261,6 +261,7 @@ struct mi_ctx {
     int opt_jk_nt = 1;       // nontemporal loads for the tile stream
     double opt_grad_dtol = 1e-13; // gradient: skip quartets with q_ab q_cd max|G| below this (0: Schwarz only)
     int opt_xf_mfma_min = 300; // transform kernel: MFMA tiles only when the spherical block has at least this many elements
+    double opt_tpq_maxprim = 32.0; // thread-per-quartet kernels only when the mean primitive quartets per shell quartet stay below this
     int opt_eri_tpq = 1;     // thread-per-quartet fused ERI kernels for the low angular classes (0: wave-per-quartet pair everywhere)
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
@@ -431,6 +432,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
     else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;
+    else if (k == "tpq_maxprim") c->opt_tpq_maxprim = value;
     else if (k == "xf_mfma_min") c->opt_xf_mfma_min = (int)value;   // takes effect at the next mi_eri_prepare
     else if (k == "grad_dtol") c->opt_grad_dtol = value;
     else return fail("mi_set_option: unknown key '%s'", key);
@@ -1882,7 +1884,10 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             const bool dbg = getenv("MI355_DEBUG") != nullptr && getenv("MI355_DEBUG")[0] == '2';
             double t_rys = 0.0, t_xf = 0.0;
             // low angular classes: one thread per quartet, fused Rys + HRR + cart->sph + scatter (eri_tpq_kernel)
-            if (c->opt_eri_tpq) {
+            // ... when the contraction is shallow enough: a thread walks ALL primitive quartets of its shell quartet, so deeply
+            // contracted shells (cc-pVXZ s shells: hundreds of primitive quartets) serialise and the wave-per-quartet path, which
+            // spreads them over lanes, wins (measured: benzene/cc-pVTZ 54 vs 63 ms, ibuprofen/def2-TZVP 0.40 vs 0.29 s)
+            if (c->opt_eri_tpq && B.mean_np * Kc.mean_np <= c->opt_tpq_maxprim && ntask >= 32768) {
                 TpqArgs Q{};
                 Q.bra = B.d_recs; Q.ket = Kc.d_recs; Q.prim = c->d_prim; Q.prefix = d_prefix; Q.nbra = E.nbra; Q.t0 = 0; Q.ntask = ntask;
                 Q.c2s = c->d_c2s;
@@ -4510,7 +4515,7 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 PairClass &Oc = swap ? B : Kc;   // class of the other pair (plain ket)
                 const int l1 = orient == 0 ? Dc.la : Dc.lb, l2 = orient == 0 ? Dc.lb : Dc.la;
                 const int lc = Oc.la, ldd = Oc.lb;
-                if (c->opt_eri_tpq) {   // low classes: thread per (quartet, permutation), fused (eri_tpq_grad_kernel)
+                if (c->opt_eri_tpq && B.mean_np * Kc.mean_np <= c->opt_tpq_maxprim && ntask >= 32768) {   // low classes, shallow contraction: thread per (quartet, permutation)
                     TpqGradArgs Q{};
                     Q.dplus = Dc.d_g_recs[orient][0]; Q.dminus = l1 >= 1 ? Dc.d_g_recs[orient][1] : nullptr; Q.ket = Oc.d_recs;
                     Q.prim = c->d_prim; Q.prefix = d_prefix; Q.nbra = (int)B.recs.size();
