@@ -2517,6 +2517,17 @@ __global__ void pad_density_kernel(const double *D, double *Dp, int nao, int ld)
     Dp[idx] = (r < nao && c < nao) ? D[(size_t)r * nao + c] : 0.0;
 }
 
+// D -> zero-padded [ld][ld] copy, and the J/K accumulators cleared in the same launch (one kernel instead of three per build)
+__global__ void pad_density_clear_kernel(const double *D, double *Dp, double *Jacc, double *Kacc, int nao, int ld)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ld * ld) return;
+    int r = idx / ld, c = idx - r * ld;
+    Dp[idx] = (r < nao && c < nao) ? D[(size_t)r * nao + c] : 0.0;
+    if (Jacc) Jacc[idx] = 0.0;
+    if (Kacc) Kacc[idx] = 0.0;
+}
+
 __global__ void finalize_jk_kernel(const double *Jacc, const double *Kacc, double *J, double *K, int nao, int ld)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2555,9 +2566,8 @@ extern "C" int mi_build_jk(mi_ctx *c, const double *d_D, int n_dm, double *d_J, 
     hipStream_t st = (hipStream_t)stream;
     size_t nn = (size_t)c->nao * c->nao, pp = (size_t)c->ldp * c->ldp;
     for (int m = 0; m < n_dm; m++) {
-        hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D + m * nn, c->d_Dpad, c->nao, c->ldp);
-        if (d_J) HIPCHK(hipMemsetAsync(c->d_Jacc, 0, sizeof(double) * pp, st));
-        if (d_K) HIPCHK(hipMemsetAsync(c->d_Kacc, 0, sizeof(double) * pp, st));
+        hipLaunchKernelGGL(pad_density_clear_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D + m * nn, c->d_Dpad,
+                           d_J ? c->d_Jacc : nullptr, d_K ? c->d_Kacc : nullptr, c->nao, c->ldp);
         if (launch_jk(c, d_J != nullptr, d_K != nullptr, st)) return -1;
         hipLaunchKernelGGL(finalize_jk_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, c->d_Jacc, c->d_Kacc,
                            d_J ? d_J + m * nn : nullptr, d_K ? d_K + m * nn : nullptr, c->nao, c->ldp);
@@ -2639,30 +2649,34 @@ extern "C" int mi_diis_combine(mi_ctx *c, const double *d_hist, const double *co
     return 0;
 }
 
+// Gram row of the DIIS error vectors: out[i * DIIS_NS + s] = partial dot product <hist_e[i], e> over slice s of the
+// vector (grid = n x DIIS_NS blocks; the caller adds the DIIS_NS partials in index order: deterministic, and 16x the
+// parallelism of one block per history vector).
+#define DIIS_NS 16
 __global__ __launch_bounds__(256) void diis_dots_kernel(const double *hist, const double *e, size_t nn, double *out)
 {
     __shared__ double sh[4];
     const double *h = hist + (size_t)blockIdx.x * nn;
-    // eight independent partial sums per thread: the loads of a 13k-element dot are all in flight at once
-    double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    size_t i = threadIdx.x;
-    for (; i + 7 * 256 < nn; i += 8 * 256) {
+    const size_t per = (nn + DIIS_NS - 1) / DIIS_NS, lo = per * blockIdx.y, hi = lo + per < nn ? lo + per : nn;
+    double p[4] = {0, 0, 0, 0};
+    size_t i = lo + threadIdx.x;
+    for (; i + 3 * 256 < hi; i += 4 * 256) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) p[u] = fma(h[i + u * 256], e[i + u * 256], p[u]);
+        for (int u = 0; u < 4; u++) p[u] = fma(h[i + u * 256], e[i + u * 256], p[u]);
     }
-    for (; i < nn; i += 256) p[0] = fma(h[i], e[i], p[0]);
-    double s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    for (; i < hi; i += 256) p[0] = fma(h[i], e[i], p[0]);
+    double s = (p[0] + p[1]) + (p[2] + p[3]);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) out[blockIdx.x * DIIS_NS + blockIdx.y] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 extern "C" int mi_diis_dots_dev(mi_ctx *c, const double *d_hist_e, const double *d_e, int n, double *d_out, void *stream)
 {
     if (!c || n < 1 || n > 64 || !d_out) return fail("mi_diis_dots_dev: bad argument");
     size_t nn = (size_t)c->nao * c->nao;
-    hipLaunchKernelGGL(diis_dots_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, d_hist_e, d_e, nn, d_out);
+    hipLaunchKernelGGL(diis_dots_kernel, dim3(n, DIIS_NS), dim3(256), 0, (hipStream_t)stream, d_hist_e, d_e, nn, d_out);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2672,10 +2686,16 @@ extern "C" int mi_diis_dots(mi_ctx *c, const double *d_hist_e, const double *d_e
     if (!c || n < 1 || n > 64) return fail("mi_diis_dots: bad argument");
     size_t nn = (size_t)c->nao * c->nao;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(diis_dots_kernel, dim3(n), dim3(256), 0, st, d_hist_e, d_e, nn, c->d_red);
+    hipLaunchKernelGGL(diis_dots_kernel, dim3(n, DIIS_NS), dim3(256), 0, st, d_hist_e, d_e, nn, c->d_red);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, c->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    double part[64 * DIIS_NS];
+    HIPCHK(hipMemcpyAsync(part, c->d_red, sizeof(double) * n * DIIS_NS, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < n; i++) {
+        double s = 0.0;
+        for (int q = 0; q < DIIS_NS; q++) s += part[i * DIIS_NS + q];
+        out[i] = s;
+    }
     return 0;
 }
 

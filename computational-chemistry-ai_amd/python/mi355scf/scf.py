@@ -56,10 +56,12 @@ class DeviceDIIS:
         self.count += 1
         m = min(self.count, self.space)
         if not hasattr(self, "dots_dev"):
-            self.dots_dev = torch.zeros(self.space, dtype=torch.float64, device=f.device)
+            self.dots_dev = torch.zeros(self.space * self.NS, dtype=torch.float64, device=f.device)
         self.eng.diis_dots_dev(self.E, self.E[slot], m, self.dots_dev)
         self._pending = (slot, m)
         return m
+
+    NS = 16   # partial sums per Gram-row entry (DIIS_NS of the kernel): added on the host in index order
 
     def next_slot(self):
         """History slot the next push will use: the SCF step lets its GEMMs write F' and e straight into it."""
@@ -71,14 +73,14 @@ class DeviceDIIS:
         self.count += 1
         m = min(self.count, self.space)
         if not hasattr(self, "dots_dev"):
-            self.dots_dev = torch.zeros(self.space, dtype=torch.float64, device=self.F.device)
+            self.dots_dev = torch.zeros(self.space * self.NS, dtype=torch.float64, device=self.F.device)
         self.eng.diis_dots_dev(self.E, self.E[slot], m, self.dots_dev)
         self._pending = (slot, m)
         return m
 
     def extrapolate(self, dots):
         slot, m = self._pending
-        dots = np.asarray(dots, dtype=np.float64)[:m]
+        dots = np.asarray(dots, dtype=np.float64)[:m * self.NS].reshape(m, self.NS).sum(axis=1)
         self.B[slot, :m] = dots
         self.B[:m, slot] = dots
         A = np.zeros((m + 1, m + 1))
@@ -579,7 +581,8 @@ class SCF:
             nd = 0
         n = fo.shape[0]
         nvo = max((n - st["nocc"]) * st["nocc"], 1)
-        parts = ([st["diis"].dots_dev[:nd]] if nd else []) + [part] + ([extra.reshape(1)] if extra is not None else []) \
+        ndp = nd * DeviceDIIS.NS
+        parts = ([st["diis"].dots_dev[:ndp]] if nd else []) + [part] + ([extra.reshape(1)] if extra is not None else []) \
             + ([sp2_tr] if sp2_tr is not None else [])
         packed = torch.cat(parts) if len(parts) > 1 else part
         # Sharded runs: every rank holds the same all-reduced J/K(/Vxc) and the replicated algebra above is free of atomics
@@ -589,7 +592,7 @@ class SCF:
             from . import parallel
             parallel.broadcast0(packed, self._pg)
         vals = packed.cpu().numpy()                    # the cycle's only host sync
-        pos = nd
+        pos = ndp
         e_el = float(vals[pos:pos + nb].sum())         # numpy's pairwise sum: the same order on every rank
         c2 = float(vals[pos + nb:pos + 2 * nb].sum())
         pos += 2 * nb
@@ -618,7 +621,7 @@ class SCF:
         e_tot = e_el + st["enuc"]
         # |g| = |2 F_vo| = |[F',D']|_F / sqrt(2), normalised by sqrt(n_vo) like PySCF's get_grad norm [MEM]
         gnorm = float(np.sqrt(max(c2, 0.0))) / np.sqrt(2.0) / np.sqrt(nvo)
-        st.update(dm=dm, vhf=fock - h1, fo=fo, dots=vals[:nd], e_tot=e_tot, gnorm=gnorm,
+        st.update(dm=dm, fock=fock, fo=fo, dots=vals[:ndp], e_tot=e_tot, gnorm=gnorm,
                   de=(e_tot - e_last) if e_last is not None else 0.0)
         return True
 
@@ -709,7 +712,7 @@ class SCF:
         if "mo_e" not in st:  # not converged (or max_cycle == 0): orbitals of the last Fock matrix
             e_, c_ = torch.linalg.eigh(st["fo"])
             st["mo_e"], st["mo_c"] = e_, self._Linv.T @ c_
-        self._dm, self._vhf = st["dm"], st["vhf"]
+        self._dm, self._vhf = st["dm"], st["fock"] - self._h1
         self.e_tot = float(st["e_tot"])
         self.mo_energy = st["mo_e"].cpu().numpy()
         self.mo_coeff = st["mo_c"].cpu().numpy()
