@@ -16,6 +16,9 @@ a = rng.normal(size=(n, n)); D = torch.as_tensor(a + a.T, device="cuda")
 eng = Engine(mol)
 st = eng.prepare_eri(1e-13)
 for _ in range(5):
-    J, K = eng.get_jk(D)
+    J, K = eng.get_jk(D)                      # jk_tiles_kernel<true,true,...>
 torch.cuda.synchronize()
-print("stored_bytes", st["stored_bytes"], "alg_bytes", 8 * st["n_unique_eri"] + 24 * n * n)
+for _ in range(5):
+    J, _k = eng.get_jk(D, with_k=False)       # jk_tiles_kernel<true,false,...>
+torch.cuda.synchronize()
+print("stored_bytes", st["stored_bytes"], "alg_bytes J+K", 8 * st["n_unique_eri"] + 24 * n * n, "J only", 8 * st["n_unique_eri"] + 16 * n * n)
