@@ -146,6 +146,8 @@ def test_oracle_reproduces_committed_golden_vectors():
     ("h2o", "def2-tzvp", -76.0590, 2e-4),
     ("ch4", "cc-pvdz", -40.1987, 1e-4),     # r(CH) = 1.087 A, T_d
     ("ch4", "cc-pvtz", -40.2134, 1e-4),
+    ("co", "cc-pvdz", -112.7493, 1e-4),     # r(CO) = 1.128 A (CCCBDB-style tabulation; UNVERIFIED-MEMORY, 4 decimals)
+    ("co", "cc-pvtz", -112.7804, 1.5e-4),   #   pins the carbon AND oxygen cc-pVTZ tables in one molecule
 ])
 def test_literature_rhf_energies_pin_the_remembered_tz_tables(formula, basis, e_lit, tol):
     """A wrong digit in a remembered exponent/coefficient moves these energies by far more than `tol`."""
@@ -154,11 +156,37 @@ def test_literature_rhf_energies_pin_the_remembered_tz_tables(formula, basis, e_
     if formula == "h2o":
         r, th = 0.9572, math.radians(104.52)
         atom = f"O 0 0 0; H {r * math.sin(th / 2):.6f} 0 {r * math.cos(th / 2):.6f}; H {-r * math.sin(th / 2):.6f} 0 {r * math.cos(th / 2):.6f}"
+    elif formula == "co":
+        atom = "C 0 0 0; O 0 0 1.128"
     else:
         a = 0.6276
         atom = f"C 0 0 0; H {a} {a} {a}; H {-a} {-a} {a}; H {-a} {a} {-a}; H {a} {-a} {-a}"
     res = orc.rhf(_mol(atom, basis))
     assert res["converged"] and abs(res["e_tot"] - e_lit) < tol, res["e_tot"]
+
+
+def test_atomic_uhf_energies_and_hf_limit_brackets_pin_carbon_and_oxygen_tz_tables():
+    """carbon/def2-TZVP and oxygen/cc-pVTZ.  (i) UHF energies of the 3P atoms in cc-pVTZ, remembered
+    to 4 decimals (UNVERIFIED-MEMORY): C -37.6916, O -74.8118.  (ii) def2-TZVP has no remembered molecular value, so it is
+    bracketed: the variational principle puts every basis-set energy ABOVE the Hartree-Fock limit (numerical HF: C atom UHF
+    -37.6937, O atom UHF -74.8188, CH4 -40.2171, CO -112.7909 [MEM]); a wrong digit in a remembered exponent or contraction
+    coefficient can only RAISE the energy, and def2-TZVP is known to sit at or slightly below cc-pVTZ for first-row
+    Hartree-Fock energies, so `E_limit < E(def2-TZVP) < E(cc-pVTZ) + 0.5 mHa` is a two-sided pin a few mHa wide."""
+    from oracle import oracle as orc
+    from mi355scf.mole import Mole
+    def atom_uhf(el, basis):
+        return orc.uhf(Mole(atom=f"{el} 0 0 0", basis=basis, spin=2, verbose=0).build())[0]
+    e_c, e_o = atom_uhf("C", "cc-pvtz"), atom_uhf("O", "cc-pvtz")
+    assert abs(e_c - (-37.6916)) < 1e-4, e_c
+    assert abs(e_o - (-74.8118)) < 1e-4, e_o
+    for el, e_tz, e_lim in (("C", e_c, -37.6937), ("O", e_o, -74.8188)):
+        e = atom_uhf(el, "def2-tzvp")
+        assert e_lim < e < e_tz + 5e-4, (el, e)
+    a = 0.6276
+    ch4 = f"C 0 0 0; H {a} {a} {a}; H {-a} {-a} {a}; H {-a} {a} {-a}; H {a} {-a} {-a}"
+    for atom, e_tz, e_lim in ((ch4, -40.2134, -40.2171), ("C 0 0 0; O 0 0 1.128", -112.7804, -112.7909)):
+        res = orc.rhf(_mol(atom, "def2-tzvp"))
+        assert res["converged"] and e_lim < res["e_tot"] < e_tz + 5e-4, res["e_tot"]
 
 
 def test_oracle_uhf_and_spin_functionals_known_answers():
