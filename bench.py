@@ -199,7 +199,7 @@ def main():
         traffic, source = pmc_traffic(label, alg_bytes) if world == 1 else (None, None)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": source, "ms_per_launch": ms,
-                "kernel": ("jk_tiles_kernel<true,true,true>" if stats["stored_bytes"] > (256 << 20) else "jk_tiles_pipe_kernel<true,false>"),
+                "kernel": ("jk_tiles_kernel<true,true,true>" if stats["stored_bytes"] > (256 << 20) else "jk_tiles_kernel<true,true,false>"),
                 "algorithmic_bytes": alg_bytes, "stored_bytes": stats["stored_bytes"],
                 "stored_GBps": stats["stored_bytes"] / (ms * 1e-3) / 1e9,
                 "share_of_step": ms / (dt / args.steps * 1e3)}

@@ -208,6 +208,52 @@ struct PairClass {
 struct TileInfo { int I, J, K, L; };
 struct RunRec { int J, K, L, first, count; };
 
+// ---- tile geometry.  A tile (I J|K L) is a list of rows (j, m) -- j = 0..7, m = l-pair 0..3, j-major -- of 16-byte chunks
+// {T[i,j,k,2m], T[i,j,k,2m+1]}, the chunks of a row ordered (i, k).  Off the block diagonals a row holds all bi*bk lanes.
+// Where I == J only i >= j is stored (weight 1 off the diagonal, 1/2 on it: the kernels' contractions are symmetric in
+// (i,j) for a symmetric density, so the dropped half would only repeat the kept one), where K == L only k >= 2m (elements
+// with k < l inside a kept chunk are zero).  Rows shrink accordingly and stay contiguous in lane order, so every load of the
+// digestion kernel is still a coalesced run of 16-byte chunks; the two-fold redundancy of diagonal tiles is gone from the stream.
+__host__ __device__ inline int tile_i0(bool dij, int j, int bi) { return dij ? (j < bi ? j : bi) : 0; }
+__host__ __device__ inline int tile_k0(bool dkl, int m, int bk) { return dkl ? (2 * m < bk ? 2 * m : bk) : 0; }
+__host__ __device__ inline int tile_pi(bool dij, int j, int bi)   // rows of i-lanes before row j
+{
+    if (!dij) return j * bi;
+    const int jc = j < bi ? j : bi;
+    return jc * bi - jc * (jc - 1) / 2;
+}
+__host__ __device__ inline int tile_qk(bool dkl, int m, int bk)   // k-lanes per i in the l-pairs before m
+{
+    if (!dkl) return m * bk;
+    int q = 0;
+    for (int mm = 0; mm < m; mm++) q += bk - tile_k0(true, mm, bk);
+    return q;
+}
+__host__ __device__ inline int tile_chunks(bool dij, bool dkl, int bi, int bk) { return tile_pi(dij, BLK, bi) * tile_qk(dkl, 4, bk); }
+// chunk index of (ii, jj, kk, m) inside its tile, -1 when that lane is not stored
+__host__ __device__ inline int tile_chunk(bool dij, bool dkl, int bi, int bk, int ii, int jj, int kk, int m)
+{
+    const int i0 = tile_i0(dij, jj, bi), k0 = tile_k0(dkl, m, bk);
+    if (ii < i0 || kk < k0) return -1;
+    return tile_pi(dij, jj, bi) * tile_qk(dkl, 4, bk) + (bi - i0) * tile_qk(dkl, m, bk) + (ii - i0) * (bk - k0) + (kk - k0);
+}
+// offset in doubles of element (ii,jj,kk,ll) and the weight it is stored with (0: not stored)
+// tri = false: the round-1 layout (full rows everywhere, 1/2 per block coincidence on both mirror elements)
+__host__ __device__ inline int64_t tile_elem(bool tri, bool dij, bool dkl, bool dpp, int bi, int bk, int ii, int jj, int kk, int ll, double *w)
+{
+    double wt = dpp ? 0.5 : 1.0;
+    if (!tri) {
+        if (dij) wt *= 0.5;
+        if (dkl) wt *= 0.5;
+        *w = wt;
+        return (int64_t)tile_chunk(false, false, bi, bk, ii, jj, kk, ll >> 1) * 2 + (ll & 1);
+    }
+    if (dij) { if (ii < jj) { *w = 0.0; return -1; } if (ii == jj) wt *= 0.5; }
+    if (dkl) { if (kk < ll) { *w = 0.0; return -1; } if (kk == ll) wt *= 0.5; }
+    *w = wt;
+    return (int64_t)tile_chunk(dij, dkl, bi, bk, ii, jj, kk, ll >> 1) * 2 + (ll & 1);
+}
+
 struct mi_ctx {
     int device = 0;
     int natm = 0, nbas = 0, nao = 0, nblk = 0, npad = 0;
@@ -263,6 +309,8 @@ struct mi_ctx {
     int opt_xf_mfma_min = 300; // transform kernel: MFMA tiles only when the spherical block has at least this many elements
     double opt_tpq_maxprim = 32.0; // thread-per-quartet kernels only when the mean primitive quartets per shell quartet stay below this
     int opt_eri_tpq = 1;     // thread-per-quartet fused ERI kernels for the low angular classes (0: wave-per-quartet pair everywhere)
+    int opt_tri_tiles = 1;   // block-diagonal tiles store triangular rows (0: the full-row layout of round 1); next mi_eri_prepare
+    int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
 };
@@ -431,6 +479,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_nt") c->opt_jk_nt = (int)value;
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
+    else if (k == "tri_tiles") c->opt_tri_tiles = (int)value;       // takes effect at the next mi_eri_prepare
     else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;
     else if (k == "tpq_maxprim") c->opt_tpq_maxprim = value;
     else if (k == "xf_mfma_min") c->opt_xf_mfma_min = (int)value;   // takes effect at the next mi_eri_prepare
@@ -858,6 +907,7 @@ struct XfArgs {
     // "pair" (P, unit s) is its first shell.
     double *dense_out;
     int dense_mode, dense_n;
+    int tri;                 // triangular rows in block-diagonal tiles (tile geometry)
 };
 
 // Read-only, wave-uniform operands (work-item records, tile directory, the J-L density rows) go through the
@@ -881,13 +931,10 @@ __device__ inline void put_tile(const XfArgs &A, int i, int j, int k, int l, dou
     // overlap the two dependent loads of one element with those of the next instead of serialising load-load-store chains
     int32_t t = as_const(A.tile_table)[(size_t)bij * (bij + 1) / 2 + bkl];
     if (t < 0) return;
-    double w = v;
-    if (I == J) w *= 0.5;
-    if (K == L) w *= 0.5;
-    if (bij == bkl) w *= 0.5;
     int bi = min(BLK, A.nao - I * BLK), bk = min(BLK, A.nao - K * BLK);
-    int ii = i & 7, jj = j & 7, kk = k & 7, ll = l & 7;
-    A.tiles[as_const(A.tile_off)[t] + ((size_t)((jj * 4 + (ll >> 1)) * (bi * bk) + ii * bk + kk) * 2 + (ll & 1))] = w;
+    double w;
+    const int64_t e = tile_elem(A.tri != 0, I == J, K == L, bij == bkl, bi, bk, i & 7, j & 7, k & 7, l & 7, &w);
+    if (e >= 0) A.tiles[as_const(A.tile_off)[t] + e] = w * v;
 }
 
 // MFMA = true: instantiation with the matrix-core paths for the large angular classes; MFMA = false: lean kernel for
@@ -1256,13 +1303,10 @@ __global__ __launch_bounds__(TPQ_BLOCK) void eri_tpq_kernel(TpqArgs A)
                             base_c = t >= 0 ? toff[t] : -1;
                         }
                         if (base_c < 0) continue;
-                        double wv = out[(sa * nj + sb) * NSCD + sc * nl + sd];
-                        if (I == J) wv *= 0.5;
-                        if (K == L) wv *= 0.5;
-                        if (bij == bkl) wv *= 0.5;
                         const int bi = min(BLK, nao - I * BLK), bk = min(BLK, nao - K * BLK);
-                        const int ii = i & 7, jj = j & 7, kk = k & 7, ll = l & 7;
-                        A.X.tiles[base_c + ((size_t)((jj * 4 + (ll >> 1)) * (bi * bk) + ii * bk + kk) * 2 + (ll & 1))] = wv;
+                        double w;
+                        const int64_t e = tile_elem(A.X.tri != 0, I == J, K == L, bij == bkl, bi, bk, i & 7, j & 7, k & 7, l & 7, &w);
+                        if (e >= 0) A.X.tiles[base_c + e] = w * out[(sa * nj + sb) * NSCD + sc * nl + sd];
                     }
     }
 }
@@ -1463,7 +1507,10 @@ static int launch_eri_tpq(int la, int lb, int lc, int ld, const TpqArgs &Q, hipS
 // J/K build streams for them.  Pure host code and a pure function of its arguments, so every rank derives the same plan.
 struct RunPlan { int J, K, L, count, owner; int64_t bytes; };
 
-static void plan_runs(int nao, const std::vector<double> &Qblk, double qmax, double tol, int nranks, std::vector<RunPlan> &plan)
+// doubles a tile occupies in the store: its chunks, rounded up to 256 bytes so that rows of following tiles stay sector-aligned
+static inline int64_t tile_doubles_padded(bool dij, bool dkl, int bi, int bk) { return ((int64_t)tile_chunks(dij, dkl, bi, bk) * 2 + 31) / 32 * 32; }
+
+static void plan_runs(int nao, const std::vector<double> &Qblk, double qmax, double tol, int nranks, bool tri, std::vector<RunPlan> &plan)
 {
     const int nblk = (nao + BLK - 1) / BLK, nbp = nblk * (nblk + 1) / 2;
     auto bsize = [&](int B) { return std::min(BLK, nao - B * BLK); };
@@ -1477,7 +1524,7 @@ static void plan_runs(int nao, const std::vector<double> &Qblk, double qmax, dou
                     int ij = I * (I + 1) / 2 + J;
                     if (ij < kl || Qblk[ij] * Qblk[kl] < tol) continue;
                     r.count++;
-                    r.bytes += (int64_t)BLK * 4 * bsize(I) * bk * 2 * 8;
+                    r.bytes += tile_doubles_padded(tri && I == J, tri && K == L, bsize(I), bk) * 8;
                 }
                 if (r.count) plan.push_back(r);
             }
@@ -1511,7 +1558,7 @@ extern "C" int mi_plan_shards(int nao, const double *qblk, double tol, int nrank
     double qmax = 0.0;
     for (double v : Q) qmax = std::max(qmax, v);
     std::vector<RunPlan> plan;
-    plan_runs(nao, Q, qmax, tol, nranks, plan);
+    plan_runs(nao, Q, qmax, tol, nranks, true, plan);
     for (int r = 0; r < nranks; r++) { bytes_per_rank[r] = 0; if (runs_per_rank) runs_per_rank[r] = 0; }
     for (const RunPlan &p : plan) { bytes_per_rank[p.owner] += p.bytes; if (runs_per_rank) runs_per_rank[p.owner]++; }
     return 0;
@@ -1690,7 +1737,8 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     int64_t off = 0, nuniq = 0;
     {
         std::vector<RunPlan> plan;
-        plan_runs(c->nao, Qblk, qmax, tol, nranks, plan);
+        c->tri = c->opt_tri_tiles != 0;
+        plan_runs(c->nao, Qblk, qmax, tol, nranks, c->tri != 0, plan);
         std::vector<uint8_t> present(nranks > 1 ? table.size() : 0, 0); // sharded store: slots that live on SOME rank
         for (const RunPlan &rp : plan) {
             const int J = rp.J, K = rp.K, L = rp.L, kl = K * (K + 1) / 2 + L;
@@ -1710,7 +1758,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                 c->tiles.push_back({I, J, K, L});
                 c->tile_off.push_back(off);
                 int bi = bsize(I), bj = bsize(J), bk = bsize(K), bl = bsize(L);
-                off += (int64_t)BLK * 4 * bi * bk * 2; // j is always padded to 8 rows (J==last implies I==last: rare)
+                off += tile_doubles_padded(c->tri && I == J, c->tri && K == L, bi, bk); // j is always padded to 8 rows (J==last implies I==last: rare)
                 int64_t nij = (I > J) ? (int64_t)bi * bj : (int64_t)bi * (bi + 1) / 2;
                 int64_t nkl = (K > L) ? (int64_t)bk * bl : (int64_t)bk * (bk + 1) / 2;
                 nuniq += (ij > kl) ? nij * nkl : nij * (nij + 1) / 2;
@@ -1869,7 +1917,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             X.bra = B.d_recs; X.ket = Kc.d_recs; X.Mbuf = c->d_M; X.prefix = d_prefix; X.nbra = E.nbra;
             X.ne = B.ne; X.nf = Kc.ne; X.nsab = B.nsab; X.nscd = Kc.nsab; X.nsb = 2 * B.lb + 1; X.nsd = 2 * Kc.lb + 1;
             X.work = d_work; X.ncomp = E.ncomp; X.tile_table = c->d_tile_table; X.tile_off = c->d_tile_off;
-            X.tiles = c->d_tiles; X.nao = c->nao;
+            X.tiles = c->d_tiles; X.nao = c->nao; X.tri = c->tri;
             X.check_owner = nranks > 1; X.ni = E.ni; X.nj = E.nj; X.nk = E.nk; X.nl = E.nl;
             int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
             size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
@@ -2141,6 +2189,7 @@ struct JkArgs {
     double *Jacc, *Kacc;
     int ld, nao;
     int n_cached;            // leading work items read with the default cache policy (kept in the Infinity Cache)
+    int tri;                 // triangular rows in block-diagonal tiles (tile geometry)
 };
 
 __device__ inline double red_select_xor(double a, double b, bool hi, int mask)
@@ -2163,6 +2212,80 @@ __device__ inline double reduce8(const double v[8], int lane, int m2, int m1, in
     return red_select_xor(b[0], b[1], h0, m0);
 }
 
+// One 16-byte chunk {T[i,j,k,2lp], T[i,j,k,2lp+1]} of the lane's sub-block.  DIJ / DKL: the tile lies on the I == J / K == L
+// block diagonal and stores triangular rows (tile geometry above); for <false,false> this is the plain
+// T[(j*4+lp)*bi*bk + i*bk + k] of a full tile.
+template <bool DIJ, bool DKL, bool NT>
+__device__ __forceinline__ d2_t jk_load_chunk(const d2_t *__restrict__ tile, int j, int lp, int bi, int bk, int i, int k, bool inb)
+{
+    d2_t x = {0.0, 0.0};
+    if (!DIJ && !DKL) {
+        if (inb) { const d2_t *q = tile + (i * bk + k) + (size_t)(j * 4 + lp) * (bi * bk); x = NT ? __builtin_nontemporal_load(q) : *q; }
+    } else {
+        const int i0 = tile_i0(DIJ, j, bi), k0 = tile_k0(DKL, lp, bk);
+        const int row = tile_pi(DIJ, j, bi) * tile_qk(DKL, 4, bk) + (bi - i0) * tile_qk(DKL, lp, bk);   // wave-uniform
+        if (inb && i >= i0 && k >= k0) { const d2_t *q = tile + row + (i - i0) * (bk - k0) + (k - k0); x = NT ? __builtin_nontemporal_load(q) : *q; }
+    }
+    return x;
+}
+
+// Digestion of one tile by one wave: 32 chunk loads per lane, six contractions per value, per-tile outputs.
+template <bool WITH_J, bool WITH_K, bool NT, bool DIJ, bool DKL>
+__device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, const int i, const int k, const int I0, const int J0,
+                                               const int K0, const int L0, const int ld, const int bk, const int64_t toff,
+                                               const double (&dKL)[8], const double (&dJK)[8], double (&kjl)[8][8], double (&jkl)[8],
+                                               double (&kjk)[8])
+{
+    const double *__restrict__ D = A.D;
+    const MI_CONST_AS double *Du = as_const(A.D);
+    const int bi = min(BLK, A.nao - I0);
+    const bool active = (i < bi) && (k < bk);
+    const d2_t *__restrict__ T = reinterpret_cast<const d2_t *>(A.tiles + toff);
+    double dIJ[8], dIL[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dIJ[j] = D[(size_t)(I0 + i) * ld + J0 + j];
+#pragma unroll
+    for (int l = 0; l < 8; l++) dIL[l] = D[(size_t)(I0 + i) * ld + L0 + l];
+    const double dIK = D[(size_t)(I0 + i) * ld + K0 + k];
+    double kik = 0.0, jij[8], kil[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { jij[j] = 0.0; kil[j] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        double v[8];
+#pragma unroll
+        for (int lp = 0; lp < 4; lp++) {
+            const d2_t x = jk_load_chunk<DIJ, DKL, NT>(T, j, lp, bi, bk, i, k, active);
+            v[2 * lp] = x.x; v[2 * lp + 1] = x.y;
+        }
+        const MI_CONST_AS double *dJL = Du + (size_t)(J0 + j) * ld + L0; // wave-uniform row (SGPRs)
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            const double x = v[l];
+            if (WITH_K) {
+                kik = fma(x, dJL[l], kik);
+                kil[l] = fma(x, dJK[j], kil[l]);
+                kjl[j][l] = fma(x, dIK, kjl[j][l]);
+                kjk[j] = fma(x, dIL[l], kjk[j]);
+            }
+            if (WITH_J) {
+                jij[j] = fma(x, dKL[l], jij[j]);
+                jkl[l] = fma(x, dIJ[j], jkl[l]);
+            }
+        }
+    }
+    // per-tile outputs
+    if (WITH_K) {
+        atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik);
+        double r = reduce8(kil, lane, 4, 2, 1); // lane holds l = k
+        atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + L0 + k], r);
+    }
+    if (WITH_J) {
+        double r = reduce8(jij, lane, 4, 2, 1); // lane holds j = k
+        atomicAdd(&A.Jacc[(size_t)(I0 + i) * ld + J0 + k], r);
+    }
+}
+
 template <bool WITH_J, bool WITH_K, bool NT>
 __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
 {
@@ -2170,13 +2293,12 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
     const int i = lane >> 3, k = lane & 7;
     const MI_CONST_AS int *tile_I = as_const(A.tile_I);
     const MI_CONST_AS int64_t *tile_off = as_const(A.tile_off);
-    const MI_CONST_AS double *Du = as_const(A.D);
   {
     const MI_CONST_AS RunRec *rr = as_const(A.runs) + seg;
     const RunRec R{rr->J, rr->K, rr->L, rr->first, rr->count};
     const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
     const int ld = A.ld;
-    const int bj = BLK, bk = min(BLK, A.nao - K0); // tiles are padded to 8 j-rows
+    const int bk = min(BLK, A.nao - K0); // tiles are padded to 8 j-rows
     const double *__restrict__ D = A.D;
 
     // run-invariant density rows
@@ -2196,60 +2318,36 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
     // the directory entry of tile t+1 is fetched while tile t is being digested
     int I_next = tile_I[R.first];
     int64_t off_next = tile_off[R.first];
-    for (int t = 0; t < R.count; t++) {
-        const int tid = R.first + t;
-        const int I0 = I_next * BLK;
-        const int64_t toff = off_next;
-        if (t + 1 < R.count) { I_next = tile_I[tid + 1]; off_next = tile_off[tid + 1]; }
-        const int bi = min(BLK, A.nao - I0);
-        const bool active = (i < bi) && (k < bk);
-        const d2_t *__restrict__ T = reinterpret_cast<const d2_t *>(A.tiles + toff) + (i * bk + k);
-        const int cs = bi * bk; // double2 stride between (j,lp) chunks
-        double dIJ[8], dIL[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) dIJ[j] = D[(size_t)(I0 + i) * ld + J0 + j];
-#pragma unroll
-        for (int l = 0; l < 8; l++) dIL[l] = D[(size_t)(I0 + i) * ld + L0 + l];
-        const double dIK = D[(size_t)(I0 + i) * ld + K0 + k];
-        double kik = 0.0, jij[8], kil[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { jij[j] = 0.0; kil[j] = 0.0; }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (j < bj) {
-                double v[8];
-#pragma unroll
-                for (int lp = 0; lp < 4; lp++) {
-                    d2_t x = {0.0, 0.0};
-                    if (active) x = NT ? __builtin_nontemporal_load(&T[(size_t)(j * 4 + lp) * cs]) : T[(size_t)(j * 4 + lp) * cs];
-                    v[2 * lp] = x.x; v[2 * lp + 1] = x.y;
-                }
-                const MI_CONST_AS double *dJL = Du + (size_t)(J0 + j) * ld + L0; // wave-uniform row (SGPRs)
-#pragma unroll
-                for (int l = 0; l < 8; l++) {
-                    const double x = v[l];
-                    if (WITH_K) {
-                        kik = fma(x, dJL[l], kik);
-                        kil[l] = fma(x, dJK[j], kil[l]);
-                        kjl[j][l] = fma(x, dIK, kjl[j][l]);
-                        kjk[j] = fma(x, dIL[l], kjk[j]);
-                    }
-                    if (WITH_J) {
-                        jij[j] = fma(x, dKL[l], jij[j]);
-                        jkl[l] = fma(x, dIJ[j], jkl[l]);
-                    }
-                }
-            }
+    int t = 0;
+    // only the first tile of a run can lie on the I == J diagonal (tiles of a run are ordered by I >= J); K == L holds for
+    // the whole run or not at all
+    if (A.tri && R.K == R.L) {
+        if (I_next == R.J) {
+            const int I0 = I_next * BLK;
+            const int64_t toff = off_next;
+            if (R.count > 1) { I_next = tile_I[R.first + 1]; off_next = tile_off[R.first + 1]; }
+            jk_digest_tile<WITH_J, WITH_K, NT, true, true>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
+            t = 1;
         }
-        // per-tile outputs
-        if (WITH_K) {
-            atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik);
-            double r = reduce8(kil, lane, 4, 2, 1); // lane holds l = k
-            atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + L0 + k], r);
+        for (; t < R.count; t++) {
+            const int I0 = I_next * BLK;
+            const int64_t toff = off_next;
+            if (t + 1 < R.count) { I_next = tile_I[R.first + t + 1]; off_next = tile_off[R.first + t + 1]; }
+            jk_digest_tile<WITH_J, WITH_K, NT, false, true>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
         }
-        if (WITH_J) {
-            double r = reduce8(jij, lane, 4, 2, 1); // lane holds j = k
-            atomicAdd(&A.Jacc[(size_t)(I0 + i) * ld + J0 + k], r);
+    } else {
+        if (A.tri && I_next == R.J) {
+            const int I0 = I_next * BLK;
+            const int64_t toff = off_next;
+            if (R.count > 1) { I_next = tile_I[R.first + 1]; off_next = tile_off[R.first + 1]; }
+            jk_digest_tile<WITH_J, WITH_K, NT, true, false>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
+            t = 1;
+        }
+        for (; t < R.count; t++) {
+            const int I0 = I_next * BLK;
+            const int64_t toff = off_next;
+            if (t + 1 < R.count) { I_next = tile_I[R.first + t + 1]; off_next = tile_off[R.first + t + 1]; }
+            jk_digest_tile<WITH_J, WITH_K, NT, false, false>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
         }
     }
     // per-run outputs
@@ -2294,20 +2392,28 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
 // loads with its own arithmetic): a tile is digested as two halves of 4 j-rows (16 double2 chunks per lane
 // each); while half A of tile t is being contracted, half B of tile t is in flight, and while half B is being
 // contracted, half A of tile t+1 is in flight.  Same register budget as holding one whole tile.
-template <bool NT>
-__device__ inline void jk_load_half(d2_t (&buf)[16], const d2_t *__restrict__ T, int cs, bool active, int half)
+template <bool DIJ, bool DKL, bool NT>
+__device__ __forceinline__ void jk_load_half_t(d2_t (&buf)[16], const d2_t *__restrict__ tile, int bi, int bk, int i, int k, int half)
 {
-    if (active) {
+    const bool inb = (i < bi) && (k < bk);
 #pragma unroll
-        for (int c = 0; c < 16; c++)
-            buf[c] = NT ? __builtin_nontemporal_load(&T[(size_t)(half * 16 + c) * cs]) : T[(size_t)(half * 16 + c) * cs];
+    for (int c = 0; c < 16; c++) buf[c] = jk_load_chunk<DIJ, DKL, NT>(tile, half * 4 + (c >> 2), c & 3, bi, bk, i, k, inb);
+}
+// dij / dkl: wave-uniform diagonal flags of the tile (triangular rows, tile geometry above)
+template <bool NT>
+__device__ __forceinline__ void jk_load_half(d2_t (&buf)[16], const d2_t *__restrict__ tile, int bi, int bk, int i, int k, bool dij, bool dkl,
+                                             int half)
+{
+    if (dkl) {
+        if (dij) jk_load_half_t<true, true, NT>(buf, tile, bi, bk, i, k, half);
+        else jk_load_half_t<false, true, NT>(buf, tile, bi, bk, i, k, half);
     } else {
-#pragma unroll
-        for (int c = 0; c < 16; c++) buf[c] = d2_t{0.0, 0.0};
+        if (dij) jk_load_half_t<true, false, NT>(buf, tile, bi, bk, i, k, half);
+        else jk_load_half_t<false, false, NT>(buf, tile, bi, bk, i, k, half);
     }
 }
 
-template <bool WITH_J, bool NT>
+template <bool WITH_J, bool NT, bool TRI>
 __global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
 {
     const int lane = threadIdx.x;
@@ -2339,17 +2445,17 @@ __global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
     }
 
     d2_t bufA[16], bufB[16];
+    const bool dkl = TRI && R.K == R.L;
     int I_cur = tile_I[R.first];
     int64_t off_cur = tile_off[R.first];
     {
         const int bi0 = min(BLK, A.nao - I_cur * BLK);
-        jk_load_half<NT>(bufA, reinterpret_cast<const d2_t *>(A.tiles + off_cur) + (i * bk + k), bi0 * bk, (i < bi0) && (k < bk), 0);
+        jk_load_half<NT>(bufA, reinterpret_cast<const d2_t *>(A.tiles + off_cur), bi0, bk, i, k, TRI && I_cur == R.J, dkl, 0);
     }
     for (int t = 0; t < R.count; t++) {
         const int tid = R.first + t;
         const int I0 = I_cur * BLK;
         const int bi = min(BLK, A.nao - I0);
-        const bool active = (i < bi) && (k < bk);
         const bool more = t + 1 < R.count;
         int I_nx = I_cur;
         int64_t off_nx = off_cur;
@@ -2360,7 +2466,7 @@ __global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
 #pragma unroll
         for (int l = 0; l < 8; l++) dIL[l] = D[(size_t)(I0 + i) * ld + L0 + l];
         const double dIK = D[(size_t)(I0 + i) * ld + K0 + k];
-        jk_load_half<NT>(bufB, reinterpret_cast<const d2_t *>(A.tiles + off_cur) + (i * bk + k), bi * bk, active, 1);
+        jk_load_half<NT>(bufB, reinterpret_cast<const d2_t *>(A.tiles + off_cur), bi, bk, i, k, TRI && I_cur == R.J, dkl, 1);
 
         double kik = 0.0, jij[8], kil[8];
 #pragma unroll
@@ -2387,7 +2493,7 @@ __global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
             }
             if (half == 0 && more) {
                 const int bin = min(BLK, A.nao - I_nx * BLK);
-                jk_load_half<NT>(bufA, reinterpret_cast<const d2_t *>(A.tiles + off_nx) + (i * bk + k), bin * bk, (i < bin) && (k < bk), 0);
+                jk_load_half<NT>(bufA, reinterpret_cast<const d2_t *>(A.tiles + off_nx), bin, bk, i, k, false, dkl, 0);   // only a run's first tile can have I == J
             }
         }
         atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik);
@@ -2425,21 +2531,23 @@ __global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
 // Dense (nao^4) copy of the resident tiles for post-SCF methods on small molecules (MP2 behind `pyscf.mp`): every stored
 // element is un-weighted (tiles hold 1/2 per block coincidence) and written to its eight symmetry images.
 __global__ __launch_bounds__(256) void eri_unpack_kernel(const double *tiles, const int64_t *tile_off, const TileInfo *info, int nao,
-                                                         double *out)
+                                                         int tri, double *out)
 {
     const TileInfo T = info[blockIdx.x];
     const int bi = min(BLK, nao - T.I * BLK), bk = min(BLK, nao - T.K * BLK);
     const int bij = T.I * (T.I + 1) / 2 + T.J, bkl = T.K * (T.K + 1) / 2 + T.L;
-    const double mult = (T.I == T.J ? 2.0 : 1.0) * (T.K == T.L ? 2.0 : 1.0) * (bij == bkl ? 2.0 : 1.0);
     const double *src = tiles + tile_off[blockIdx.x];
-    const int ntot = BLK * 4 * bi * bk * 2;
+    const int ntot = BLK * BLK * bi * bk;
     const size_t n1 = nao, n2 = n1 * nao, n3 = n2 * nao;
     for (int idx = threadIdx.x; idx < ntot; idx += blockDim.x) {
-        const int lo = idx & 1, t = idx >> 1, pos = t % (bi * bk), jl = t / (bi * bk);
-        const int ii = pos / bk, kk = pos - ii * bk, jj = jl >> 2, ll = (jl & 3) * 2 + lo;
+        const int ll = idx & 7, jj = (idx >> 3) & 7, pos = idx >> 6;
+        const int ii = pos / bk, kk = pos - ii * bk;
         const size_t i = T.I * BLK + ii, j = T.J * BLK + jj, k = T.K * BLK + kk, l = T.L * BLK + ll;
         if (j >= n1 || l >= n1) continue;
-        const double v = mult * src[idx];
+        double w;
+        const int64_t e = tile_elem(tri != 0, T.I == T.J, T.K == T.L, bij == bkl, bi, bk, ii, jj, kk, ll, &w);
+        if (e < 0) continue;                      // the (j,i) / (l,k) partner writes this image
+        const double v = src[e] / w;
         out[i * n3 + j * n2 + k * n1 + l] = v; out[j * n3 + i * n2 + k * n1 + l] = v;
         out[i * n3 + j * n2 + l * n1 + k] = v; out[j * n3 + i * n2 + l * n1 + k] = v;
         out[k * n3 + l * n2 + i * n1 + j] = v; out[l * n3 + k * n2 + i * n1 + j] = v;
@@ -2459,7 +2567,7 @@ extern "C" int mi_eri_unpack(mi_ctx *c, double *d_out, void *stream)
     if (c->n_tiles == 0) return 0;
     TileInfo *d_info = nullptr;
     if (upload(&d_info, c->tiles)) return -1;
-    hipLaunchKernelGGL(eri_unpack_kernel, dim3((unsigned)c->n_tiles), dim3(256), 0, st, c->d_tiles, c->d_tile_off, d_info, c->nao, d_out);
+    hipLaunchKernelGGL(eri_unpack_kernel, dim3((unsigned)c->n_tiles), dim3(256), 0, st, c->d_tiles, c->d_tile_off, d_info, c->nao, c->tri, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     hipFree(d_info);
@@ -2469,7 +2577,7 @@ extern "C" int mi_eri_unpack(mi_ctx *c, double *d_out, void *stream)
 // One shell quartet (ish jsh|ksh lsh) read back from the resident tiles: element -> canonical tile position (the inverse of
 // put_tile), un-weighted.  NaN where the tile is not resident on this rank (sharded store), 0 where it was screened out.
 __global__ void eri_read_quartet_kernel(const double *tiles, const int64_t *tile_off, const int32_t *table, int nao, int ai, int ni,
-                                        int aj, int nj, int ak, int nk, int al, int nl, const uint8_t *present, double *out)
+                                        int aj, int nj, int ak, int nk, int al, int nl, const uint8_t *present, int tri, double *out)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ni * nj * nk * nl) return;
@@ -2483,10 +2591,13 @@ __global__ void eri_read_quartet_kernel(const double *tiles, const int64_t *tile
     const size_t slot = (size_t)bij * (bij + 1) / 2 + bkl;
     const int32_t t = table[slot];
     if (t < 0) { out[idx] = (present && present[slot]) ? __builtin_nan("") : 0.0; return; }
-    const double mult = (I == J ? 2.0 : 1.0) * (K == L ? 2.0 : 1.0) * (bij == bkl ? 2.0 : 1.0);
     const int bi = min(BLK, nao - I * BLK), bk = min(BLK, nao - K * BLK);
-    const int ii = i & 7, jj = j & 7, kk = k & 7, ll = l & 7;
-    out[idx] = mult * tiles[tile_off[t] + ((size_t)((jj * 4 + (ll >> 1)) * (bi * bk) + ii * bk + kk) * 2 + (ll & 1))];
+    int ii = i & 7, jj = j & 7, kk = k & 7, ll = l & 7;
+    if (tri && I == J && ii < jj) { int t_ = ii; ii = jj; jj = t_; }
+    if (tri && K == L && kk < ll) { int t_ = kk; kk = ll; ll = t_; }
+    double w;
+    const int64_t e = tile_elem(tri != 0, I == J, K == L, bij == bkl, bi, bk, ii, jj, kk, ll, &w);
+    out[idx] = tiles[tile_off[t] + e] / w;
 }
 
 extern "C" int mi_eri_read_quartet(mi_ctx *c, int ish, int jsh, int ksh, int lsh, double *out)
@@ -2502,7 +2613,7 @@ extern "C" int mi_eri_read_quartet(mi_ctx *c, int ish, int jsh, int ksh, int lsh
     double *d_out = nullptr;
     HIPCHK(hipMalloc(&d_out, sizeof(double) * tot));
     hipLaunchKernelGGL(eri_read_quartet_kernel, dim3((tot + 255) / 256), dim3(256), 0, nullptr, c->d_tiles, c->d_tile_off, c->d_tile_table,
-                       c->nao, ao[0], n[0], ao[1], n[1], ao[2], n[2], ao[3], n[3], c->d_tile_present, d_out);
+                       c->nao, ao[0], n[0], ao[1], n[1], ao[2], n[2], ao[3], n[3], c->d_tile_present, c->tri, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, d_out, sizeof(double) * tot, hipMemcpyDeviceToHost));
     hipFree(d_out);
@@ -2540,19 +2651,21 @@ __global__ void finalize_jk_kernel(const double *Jacc, const double *Kacc, doubl
 static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
 {
     JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao,
-             c->n_jk_cached};
+             c->n_jk_cached, c->tri};
     if (c->n_tiles == 0) return 0;
     dim3 g(A.nruns), b(64);
     // nontemporal loads only when the tensor cannot stay in the 256 MiB Infinity Cache between SCF cycles
     const bool nt = c->opt_jk_nt != 0 && (c->opt_jk_nt > 1 || c->tile_doubles * 8 > ((int64_t)256 << 20));
-    const bool pipe = c->opt_jk_pipe > 0 || (c->opt_jk_pipe < 0 && c->tile_doubles * 8 <= ((int64_t)256 << 20));
+    // the half-tile pipeline only exists for full-row tiles: with triangular rows (the default) the plain kernel is the faster
+    // one on cache-resident tensors too (benzene/cc-pVDZ J+K 39.8 us vs 41.5 us for full rows + pipeline, 48 us for both)
+    const bool pipe = !c->tri && (c->opt_jk_pipe > 0 || (c->opt_jk_pipe < 0 && c->tile_doubles * 8 <= ((int64_t)256 << 20)));
     if (pipe && wk) {
-        if (wj) { if (nt) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, false>), g, b, 0, st, A); }
-        else hipLaunchKernelGGL((jk_tiles_pipe_kernel<false, true>), g, b, 0, st, A);
+        if (wj) { if (nt) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, true, false>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, false, false>), g, b, 0, st, A); }
+        else hipLaunchKernelGGL((jk_tiles_pipe_kernel<false, true, false>), g, b, 0, st, A);
     }
     else if (wj && wk) { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<true, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<true, true, false>), g, b, 0, st, A); }
-    else if (wj) hipLaunchKernelGGL((jk_tiles_kernel<true, false, true>), g, b, 0, st, A);
-    else hipLaunchKernelGGL((jk_tiles_kernel<false, true, true>), g, b, 0, st, A);
+    else if (wj) { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<true, false, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<true, false, false>), g, b, 0, st, A); }
+    else { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<false, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<false, true, false>), g, b, 0, st, A); }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -3,7 +3,7 @@
 
 Same grid, AO, density and V_xc HIP kernels as RKS; the functional is evaluated by `mi_xc_eval_spin` (forward-mode
 dual numbers over rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb: spin-scaled exchange, VWN/PW92 spin interpolation,
-open-shell LYP, PBE correlation with phi(zeta)).  Meta-GGAs (the template's default M06-2X) are not implemented.
+open-shell LYP, PBE correlation with phi(zeta)).  Meta-GGAs (TPSS; the template's default M06-2X, parameter tables unverified-memory) go through `mi_xc_eval_mgga_spin` (dual numbers incl. tau_a, tau_b).
 The grid is not pruned by density (PySCF's `small_rho_cutoff` step is RKS-only here).
 """
 import numpy as np
