@@ -941,11 +941,24 @@ __device__ inline void put_tile(const XfArgs &A, int i, int j, int k, int l, dou
 // the small classes that make up most quartets.  GSZ = lanes per quartet (64, or 16 = four quartets per wave, as
 // in eri_rys_kernel).  (Four waves sharing a quartet's LDS blocks were measured slower: 0.50 vs 0.46 s for
 // ibuprofen/def2-TZVP.)
+// element (i,j,k,l) of one symmetry image whose tile base (-1: no resident canonical tile) is already known
+__device__ inline void put_tile_at(const XfArgs &A, int64_t base, int i, int j, int k, int l, double v)
+{
+    if (base < 0) return;
+    const int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
+    const int bij = I * (I + 1) / 2 + J, bkl = K * (K + 1) / 2 + L;
+    const int bi = min(BLK, A.nao - I * BLK), bk = min(BLK, A.nao - K * BLK);
+    double w;
+    const int64_t e = tile_elem(A.tri != 0, I == J, K == L, bij == bkl, bi, bk, i & 7, j & 7, k & 7, l & 7, &w);
+    if (e >= 0) A.tiles[base + e] = w * v;
+}
+
 template <bool MFMA, int GSZ>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void eri_transform_scatter(XfArgs A)
 {
     extern __shared__ double lds_all[];
     constexpr int QPW = 64 / GSZ;
+    __shared__ int64_t tbase_all[QPW][8][16];   // tile base per (symmetry image, 2x2x2x2 sub-block of the quartet's AO ranges)
     const int grp = threadIdx.x / GSZ, lane = threadIdx.x % GSZ;
     const int64_t tl = (int64_t)blockIdx.x * QPW + grp;
     bool live = tl < A.ntask;
@@ -958,21 +971,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const double *E0g = A.work + (size_t)tl * A.ncomp;
     double *E0 = lds_all + (size_t)grp * ((size_t)A.ne * A.nf + (size_t)A.nsab * A.nf); // [ne][nf]
     double *X = E0 + A.ne * A.nf;                                                       // [nsab][nf]
+    // (M_ab / M_cd^T staged in LDS as well was measured SLOWER -- ibuprofen/def2-TZVP 0.325 -> 0.342 s: this kernel is bound by
+    // its scattered tile stores, see DESIGN.md 3.2, and the larger LDS footprint only costs occupancy)
+    const double *Mab = A.Mbuf + ab.m_off, *Mcd = A.Mbuf + cd.m_off;
+    const double *MabT = Mab + A.nsab * A.ne, *McdT = Mcd + A.nscd * A.nf;   // [e][r], [f][c]
     if (live)
         for (int c = lane; c < A.ne * A.nf; c += GSZ) E0[c] = E0g[c];
-    __syncthreads();
-    const double *Mab = A.Mbuf + ab.m_off, *Mcd = A.Mbuf + cd.m_off;
-    // which of the 8 index images can land in a canonical tile (I >= J, K >= L) at all: decided once per quartet
-    // from the block ranges of the four shells (necessary condition; put_tile still checks each element)
-    unsigned mask;
-    {
-        const int ni = A.nsab / A.nsb, nj = A.nsb, nk = A.nscd / A.nsd, nl = A.nsd;
-        const int lo[4] = {ab.ao_i >> 3, ab.ao_j >> 3, cd.ao_i >> 3, cd.ao_j >> 3};
-        const int hi[4] = {(ab.ao_i + ni - 1) >> 3, (ab.ao_j + nj - 1) >> 3, (cd.ao_i + nk - 1) >> 3, (cd.ao_j + nl - 1) >> 3};
-        auto ok = [&](int a, int b, int c, int d) { return hi[a] >= lo[b] && hi[c] >= lo[d]; };
-        mask = (ok(0, 1, 2, 3) ? 1u : 0u) | (ok(1, 0, 2, 3) ? 2u : 0u) | (ok(0, 1, 3, 2) ? 4u : 0u) | (ok(1, 0, 3, 2) ? 8u : 0u) |
-               (ok(2, 3, 0, 1) ? 16u : 0u) | (ok(3, 2, 0, 1) ? 32u : 0u) | (ok(2, 3, 1, 0) ? 64u : 0u) | (ok(3, 2, 1, 0) ? 128u : 0u);
+    // symmetry images: role of (a0,a1,a2,a3) = (ab.i, ab.j, cd.i, cd.j) in (i,j,k,l); bit 0 swaps the bra pair, bit 1 the ket
+    // pair, bit 2 exchanges bra and ket.  Which images can land in a canonical tile (I >= J, K >= L) at all is decided once per
+    // quartet from the block ranges of the four shells, and so is the tile of every sub-block: the directory look-ups (two
+    // dependent global loads) happen 128 times per quartet in parallel instead of once per element and image in sequence.
+    const int nsh[4] = {A.nsab / A.nsb, A.nsb, A.nscd / A.nsd, A.nsd};
+    const int aos[4] = {ab.ao_i, ab.ao_j, cd.ao_i, cd.ao_j};
+    int lo[4], hi[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { lo[q] = aos[q] >> 3; hi[q] = (aos[q] + nsh[q] - 1) >> 3; }
+    auto ok = [&](int a, int b, int c, int d) { return hi[a] >= lo[b] && hi[c] >= lo[d]; };
+    const unsigned mask = (ok(0, 1, 2, 3) ? 1u : 0u) | (ok(1, 0, 2, 3) ? 2u : 0u) | (ok(0, 1, 3, 2) ? 4u : 0u) | (ok(1, 0, 3, 2) ? 8u : 0u) |
+                          (ok(2, 3, 0, 1) ? 16u : 0u) | (ok(3, 2, 0, 1) ? 32u : 0u) | (ok(2, 3, 1, 0) ? 64u : 0u) | (ok(3, 2, 1, 0) ? 128u : 0u);
+    int64_t (*tbase)[16] = tbase_all[grp];
+    if (live && !A.dense_mode) {
+        for (int idx = lane; idx < 128; idx += GSZ) {
+            const int img = idx >> 4;
+            int64_t base = -1;
+            if (mask & (1u << img)) {
+                // blocks of the four shells in their own order, then permuted like the indices of this image
+                int blk[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) blk[q] = lo[q] + ((idx >> q) & 1);
+                const bool valid = blk[0] <= hi[0] && blk[1] <= hi[1] && blk[2] <= hi[2] && blk[3] <= hi[3];
+                // emit() numbers the exchanged images (l,k,i,j) = 5 and (k,l,j,i) = 6: pair swaps are applied AFTER the exchange there
+                const int f = img == 5 ? 6 : (img == 6 ? 5 : img);
+                int r0 = (f & 1) ? 1 : 0, r1 = (f & 1) ? 0 : 1, r2 = (f & 2) ? 3 : 2, r3 = (f & 2) ? 2 : 3;
+                if (f & 4) { int t_ = r0; r0 = r2; r2 = t_; t_ = r1; r1 = r3; r3 = t_; }
+                const int I = blk[r0], J = blk[r1], K = blk[r2], L = blk[r3];
+                if (valid && I >= J && K >= L) {
+                    const int bij = I * (I + 1) / 2 + J, bkl = K * (K + 1) / 2 + L;
+                    if (bij >= bkl) {
+                        const int32_t t = A.tile_table[(size_t)bij * (bij + 1) / 2 + bkl];
+                        if (t >= 0) base = A.tile_off[t];
+                    }
+                }
+            }
+            tbase[img][idx & 15] = base;
+        }
     }
+    __syncthreads();
     auto emit = [&](int r, int c, double s) {
         int sa = r / A.nsb, sb = r - sa * A.nsb, sc = c / A.nsd, sd = c - sc * A.nsd;
         int i = ab.ao_i + sa, j = ab.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
@@ -986,20 +1030,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             A.dense_out[(size_t)k * A.dense_n + i] = s;
             return;
         }
-        if (mask & 1) put_tile(A, i, j, k, l, s);
-        if (mask & 2) put_tile(A, j, i, k, l, s);
-        if (mask & 4) put_tile(A, i, j, l, k, s);
-        if (mask & 8) put_tile(A, j, i, l, k, s);
-        if (mask & 16) put_tile(A, k, l, i, j, s);
-        if (mask & 32) put_tile(A, l, k, i, j, s);
-        if (mask & 64) put_tile(A, k, l, j, i, s);
-        if (mask & 128) put_tile(A, l, k, j, i, s);
+        // sub-block of this element in the shells' own order (bit q: second block of shell q's AO range)
+        const int sub = ((i >> 3) - lo[0]) | (((j >> 3) - lo[1]) << 1) | (((k >> 3) - lo[2]) << 2) | (((l >> 3) - lo[3]) << 3);
+        if (mask & 1) put_tile_at(A, tbase[0][sub], i, j, k, l, s);
+        if (mask & 2) put_tile_at(A, tbase[1][sub], j, i, k, l, s);
+        if (mask & 4) put_tile_at(A, tbase[2][sub], i, j, l, k, s);
+        if (mask & 8) put_tile_at(A, tbase[3][sub], j, i, l, k, s);
+        if (mask & 16) put_tile_at(A, tbase[4][sub], k, l, i, j, s);
+        if (mask & 32) put_tile_at(A, tbase[5][sub], l, k, i, j, s);
+        if (mask & 64) put_tile_at(A, tbase[6][sub], k, l, j, i, s);
+        if (mask & 128) put_tile_at(A, tbase[7][sub], l, k, j, i, s);
     };
     // X = Mab E0, out = X Mcd^T: FP64 MFMA tiles for the large angular classes, per-lane dot products otherwise
     if (MFMA && GSZ == 64 && mfma_worthwhile(A.nsab, A.nf, A.ne)) {
         for (int m0 = 0; m0 < A.nsab; m0 += 16)
             for (int n0 = 0; n0 < A.nf; n0 += 16) {
-                d4_t x = wave_mfma_tile(Mab + A.nsab * A.ne /* M^T [e][r] */, 1, A.nsab, A.nsab, E0, A.nf, 1, A.nf, A.ne, m0, n0, lane);
+                d4_t x = wave_mfma_tile(MabT /* M^T [e][r] */, 1, A.nsab, A.nsab, E0, A.nf, 1, A.nf, A.ne, m0, n0, lane);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     int r = m0 + (lane >> 4) + 4 * q, f = n0 + (lane & 15);
@@ -1018,7 +1064,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     if (MFMA && GSZ == 64 && mfma_worthwhile(A.nsab, A.nscd, A.nf)) {
         for (int m0 = 0; m0 < A.nsab; m0 += 16)
             for (int n0 = 0; n0 < A.nscd; n0 += 16) {
-                d4_t o4 = wave_mfma_tile(X, A.nf, 1, A.nsab, Mcd + A.nscd * A.nf /* M^T [f][c] */, A.nscd, 1, A.nscd, A.nf, m0, n0, lane);
+                d4_t o4 = wave_mfma_tile(X, A.nf, 1, A.nsab, McdT /* M^T [f][c] */, A.nscd, 1, A.nscd, A.nf, m0, n0, lane);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     int r = m0 + (lane >> 4) + 4 * q, c = n0 + (lane & 15);
@@ -1029,7 +1075,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         for (int o = lane; o < A.nsab * A.nscd; o += GSZ) {
             int r = o / A.nscd, c = o - r * A.nscd;
             double s = 0.0;
-            for (int f = 0; f < A.nf; f++) s += X[r * A.nf + f] * Mcd[c * A.nf + f];
+            for (int f = 0; f < A.nf; f++) s += X[r * A.nf + f] * McdT[f * A.nscd + c];
             emit(r, c, s);
         }
     }
@@ -4727,6 +4773,8 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                         hipLaunchKernelGGL((eri_grad_contract<16, false>), dim3((nb + 3) / 4), dim3(64), shm * 4, st, X);
                     } else if (mfma_worthwhile(X.ns1 * X.ns2, X.nf, X.nscd) || mfma_worthwhile(X.ns1 * X.ns2, X.ne_p, X.nf) ||
                                (has_m && mfma_worthwhile(X.ns1 * X.ns2, X.ne_m, X.nf))) {
+                        // (two or four waves sharing one quartet's LDS blocks -- eri_grad_contract<128|256, true> -- were measured at
+                        // -2 % / +8 %: the kernel is parked on its dependent load chain, 70 % of wave cycles, not short of lanes)
                         if (shm > 64 * 1024)
                             HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
                         hipLaunchKernelGGL((eri_grad_contract<64, true>), dim3(nb), dim3(64), shm, st, X);

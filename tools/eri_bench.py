@@ -34,6 +34,9 @@ if "--grad" in sys.argv:   # derivative-ERI contraction with a converged RHF den
     mf = RHF(mol); mf.kernel()
     if "--quiet" not in sys.argv:
         os.environ["MI355_DEBUG"] = "1"
+    for kv in os.environ.get("ERI_OPTS", "").split(","):
+        if "=" in kv:
+            mf.engine.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     D = torch.as_tensor(mf.make_rdm1(), device="cuda")
     g = torch.zeros(mol.natm, 3, dtype=torch.float64, device="cuda")
     for hyb in (1.0, 0.2):
