@@ -2840,6 +2840,101 @@ extern "C" int mi_diis_dots_dev(mi_ctx *c, const double *d_hist_e, const double 
     return 0;
 }
 
+// CDIIS without the host: one small workgroup adds the Gram-row partials of the newest error vector in index order, updates the
+// device-resident B matrix (row and column `slot` of [space][space]) and solves Pulay's (m+1) x (m+1) system
+//   [0 1^T; 1 B] [lambda; c] = [1; 0]
+// by Gaussian elimination with partial pivoting (what LAPACK's dgesv behind numpy.linalg.solve does in PySCF's
+// scf.diis -> lib.diis [MEM]); c[0..m) goes to d_coef for diis_combine_dev_kernel.  A singular or non-finite system (error
+// vectors exactly zero) falls back to c = e_slot, i.e. no extrapolation.  Same instruction sequence on every rank of a
+// sharded run, so the coefficients are bit-identical there.
+#define DIIS_MAXM 16
+__global__ __launch_bounds__(64) void diis_solve_kernel(const double *part, int m, int slot, int space, double *B, double *coef)
+{
+    __shared__ double A[DIIS_MAXM + 1][DIIS_MAXM + 2];
+    const int t = threadIdx.x;
+    if (t < m) {
+        double s = 0.0;
+        for (int q = 0; q < DIIS_NS; q++) s += part[t * DIIS_NS + q];
+        B[slot * space + t] = s;
+        B[t * space + slot] = s;
+    }
+    __syncthreads();
+    const int n = m + 1;
+    for (int idx = t; idx < n * (n + 1); idx += 64) {
+        const int i = idx / (n + 1), j = idx - i * (n + 1);
+        double v;
+        if (j == n) v = (i == 0) ? 1.0 : 0.0;
+        else if (i == 0) v = (j == 0) ? 0.0 : 1.0;
+        else if (j == 0) v = 1.0;
+        else v = B[(i - 1) * space + (j - 1)];
+        A[i][j] = v;
+    }
+    __syncthreads();
+    // elimination with the rows spread over the lanes (lane i owns row i): 9 short steps instead of a serial triple loop
+    __shared__ int piv_s;
+    __shared__ int ok_s;
+    if (t == 0) ok_s = 1;
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+        if (t == 0) {
+            int p = k;
+            double big = fabs(A[k][k]);
+            for (int i = k + 1; i < n; i++) if (fabs(A[i][k]) > big) { big = fabs(A[i][k]); p = i; }
+            if (!(big > 0.0) || !isfinite(big)) ok_s = 0;
+            piv_s = p;
+        }
+        __syncthreads();
+        if (!ok_s) break;
+        const int p = piv_s;
+        if (p != k && t <= n) { double tmp = A[k][t]; A[k][t] = A[p][t]; A[p][t] = tmp; }   // lane t swaps column t of the two rows
+        __syncthreads();
+        if (t > k && t < n) {
+            const double f = A[t][k] / A[k][k];
+            if (f != 0.0) for (int j = k; j <= n; j++) A[t][j] -= f * A[k][j];
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    bool ok = ok_s != 0;
+    double x[DIIS_MAXM + 1];
+    if (ok) {
+        for (int i = n - 1; i >= 0; i--) {
+            double sx = A[i][n];
+            for (int j = i + 1; j < n; j++) sx -= A[i][j] * x[j];
+            x[i] = sx / A[i][i];
+            if (!isfinite(x[i])) ok = false;
+        }
+    }
+    for (int i = 0; i < m; i++) coef[i] = ok ? x[i + 1] : (i == slot ? 1.0 : 0.0);
+}
+
+extern "C" int mi_diis_solve(mi_ctx *c, const double *d_part, int m, int slot, int space, double *d_B, double *d_coef, void *stream)
+{
+    if (!c || !d_part || !d_B || !d_coef || m < 1 || m > DIIS_MAXM || space < m || slot < 0 || slot >= m) return fail("mi_diis_solve: bad argument");
+    hipLaunchKernelGGL(diis_solve_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_part, m, slot, space, d_B, d_coef);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+__global__ void diis_combine_dev_kernel(const double *hist, const double *coef, int n, size_t nn, double *out)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nn) return;
+    const MI_CONST_AS double *cf = as_const(coef);
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s = fma(cf[i], hist[(size_t)i * nn + idx], s);
+    out[idx] = s;
+}
+
+extern "C" int mi_diis_combine_dev(mi_ctx *c, const double *d_hist, const double *d_coef, int n, double *d_out, void *stream)
+{
+    if (!c || !d_hist || !d_coef || !d_out || n < 1 || n > DIIS_MAXM) return fail("mi_diis_combine_dev: bad argument");
+    size_t nn = (size_t)c->nao * c->nao;
+    hipLaunchKernelGGL(diis_combine_dev_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_hist, d_coef, n, nn, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mi_diis_dots(mi_ctx *c, const double *d_hist_e, const double *d_e, int n, double *out, void *stream)
 {
     if (!c || n < 1 || n > 64) return fail("mi_diis_dots: bad argument");
@@ -4823,7 +4918,7 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
 // t%16 + 16 m of both panels: no integer division, 128-byte segments per row and instruction.
 // PLAN = true: the step is a quadratic fixed by the host, Xc = ca X2p + cb Xp + cc I (no dependence on the previous
 // launch's traces; `first`: Xc = cb Xp + cc I, the affine map of the Fock matrix); PLAN = false: trace-correcting SP2.
-struct Sp2Coef { double a, b, c; };
+struct Sp2Coef { double a, b, c; double out_scale; };   // out_scale: factor on the stored X (0 = 1); the traces stay those of X
 template <int MAXM, bool PLAN>
 __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *__restrict__ Xp, const double *__restrict__ X2p,
                                                         const double *__restrict__ trp, int first, int n, int kpad, double target,
@@ -4835,7 +4930,14 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *__restrict
     double *Pb = lds + 16 * (kpad + 4);     // [16][kpad+4]  rows j0..j0+15 of Xc
     double *red = Pb + 16 * (kpad + 4);     // [4][256]  (its first 64 doubles also stage the partial traces)
     const int ldp = kpad + 4;               // +4 doubles: breaks the power-of-two LDS row stride
-    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    // X and X^2 are symmetric: only the tiles (I >= J) are computed (grid = nb(nb+1)/2 workgroups -- 153 for N = 264, one round
+    // on 256 CUs instead of 289 in two) and every off-diagonal tile is stored with its mirror image.  The mirrored values are
+    // bit-identical to what the (J, I) workgroup used to compute (same products, same k order).
+    int bI = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((bI + 1) * (bI + 2) / 2 <= (int)blockIdx.x) bI++;
+    while (bI * (bI + 1) / 2 > (int)blockIdx.x) bI--;
+    const int bJ = (int)blockIdx.x - bI * (bI + 1) / 2;
+    const int i0 = bI * 16, j0 = bJ * 16;
     const int t = threadIdx.x, r = t >> 4, c = t & 15;
     const int nbd = (n + 15) / 16;
     // partial traces of the previous launch: ONE coalesced load (thread b <- slot b), staged in LDS and added in index order
@@ -4901,13 +5003,18 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *__restrict
             if (gi < n && gj < n) {
                 X2c[(size_t)gi * n + gj] = v;
                 double xc = Pa[row * ldp + gj];
-                Xc[(size_t)gi * n + gj] = xc;
+                const double osc = (PLAN && cf.out_scale != 0.0) ? cf.out_scale : 1.0;
+                Xc[(size_t)gi * n + gj] = osc * xc;
+                if (bI != bJ) {
+                    X2c[(size_t)gj * n + gi] = v;
+                    Xc[(size_t)gj * n + gi] = osc * Pb[col * ldp + gi];
+                }
                 if (gi == gj) { tr2 += v; tr1 += xc; }
             }
         }
-        if (blockIdx.x == blockIdx.y) {
+        if (bI == bJ) {
             for (int o = 32; o > 0; o >>= 1) { tr1 += __shfl_xor(tr1, o); tr2 += __shfl_xor(tr2, o); }
-            if (lane == 0) { trc[2 * blockIdx.x] = tr1; trc[2 * blockIdx.x + 1] = tr2; }
+            if (lane == 0) { trc[2 * bI] = tr1; trc[2 * bI + 1] = tr2; }
         }
     }
 }
@@ -4937,7 +5044,7 @@ extern "C" int mi_sp2_iterate(mi_ctx *c, double *d_X, double *d_X2, int nit, dou
     const int kpad = ((n + 15) / 16) * 16;
     const size_t shm = sizeof(double) * (2 * 16 * (kpad + 4) + 4 * 256);
     const int nb = (n + 15) / 16;
-    dim3 grid(nb, nb), block(256);
+    dim3 grid(nb * (nb + 1) / 2), block(256);
     const size_t nn = (size_t)n * n;
     (void)have_x2; // X^2 and the traces of the incoming X are always (re)derived by the first pass
     constexpr int TS = 2 * SP2_TRS;
@@ -4973,7 +5080,7 @@ extern "C" int mi_sp2_iterate_pingpong(mi_ctx *c, double *d_A, double *d_B, int 
     const int kpad = ((n + 15) / 16) * 16;
     const size_t shm = sizeof(double) * (2 * 16 * (kpad + 4) + 4 * 256);
     const int nb = (n + 15) / 16;
-    dim3 grid(nb, nb), block(256);
+    dim3 grid(nb * (nb + 1) / 2), block(256);
     const size_t nn = (size_t)n * n;
     constexpr int TS = 2 * SP2_TRS;
     const sp2_fused_fn sp2_fused_kernel = sp2_fused_for(kpad);
@@ -4997,8 +5104,8 @@ extern "C" int mi_sp2_iterate_pingpong(mi_ctx *c, double *d_A, double *d_B, int 
 // Pass 0 maps the Fock matrix, X_0 = coef[1] F + coef[2] I; pass k = 1..nit applies X_k = a X_{k-1}^2 + b X_{k-1} + c I
 // (coef[3k..3k+2]); every pass also leaves X_k^2 and the partial traces (validation by the caller: tr(X - X^2), tr X).
 // d_F is only read; d_A, d_B: two [X | X2] buffers of 2 n^2 doubles; *d_res = the one holding {X_nit, X_nit^2}.
-extern "C" int mi_sp2_iterate_planned(mi_ctx *c, const double *d_F, double *d_A, double *d_B, int nit, const double *coef, double *d_tr,
-                                      double **d_tr_out, double **d_res, void *stream)
+extern "C" int mi_sp2_iterate_planned(mi_ctx *c, const double *d_F, double *d_A, double *d_B, int nit, const double *coef, double out_scale,
+                                      double *d_tr, double **d_tr_out, double **d_res, void *stream)
 {
     if (!c || !d_F || !d_A || !d_B || !coef || !d_tr || !d_tr_out || !d_res || nit < 0) return fail("mi_sp2_iterate_planned: bad argument");
     const int n = c->nao;
@@ -5007,15 +5114,16 @@ extern "C" int mi_sp2_iterate_planned(mi_ctx *c, const double *d_F, double *d_A,
     const int kpad = ((n + 15) / 16) * 16;
     const size_t shm = sizeof(double) * (2 * 16 * (kpad + 4) + 4 * 256);
     const int nb = (n + 15) / 16;
-    dim3 grid(nb, nb), block(256);
+    dim3 grid(nb * (nb + 1) / 2), block(256);
     const size_t nn = (size_t)n * n;
     constexpr int TS = 2 * SP2_TRS;
     const sp2_fused_fn kern = sp2_fused_for_t<true>(kpad);
     double *cur = d_A, *nxt = d_B;
-    hipLaunchKernelGGL(kern, grid, block, shm, st, d_F, d_F, d_tr, 1, n, kpad, 0.0, cur, cur + nn, d_tr, Sp2Coef{0.0, coef[1], coef[2]});
+    hipLaunchKernelGGL(kern, grid, block, shm, st, d_F, d_F, d_tr, 1, n, kpad, 0.0, cur, cur + nn, d_tr,
+                       Sp2Coef{0.0, coef[1], coef[2], nit == 0 ? out_scale : 0.0});
     for (int it = 1; it <= nit; it++) {
         hipLaunchKernelGGL(kern, grid, block, shm, st, cur, cur + nn, d_tr, 0, n, kpad, 0.0, nxt, nxt + nn, d_tr + TS * it,
-                           Sp2Coef{coef[3 * it], coef[3 * it + 1], coef[3 * it + 2]});
+                           Sp2Coef{coef[3 * it], coef[3 * it + 1], coef[3 * it + 2], it == nit ? out_scale : 0.0});
         std::swap(cur, nxt);
     }
     HIPCHK(hipGetLastError());

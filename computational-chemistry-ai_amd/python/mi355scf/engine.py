@@ -74,6 +74,8 @@ def lib():
         L.mi_diis_combine.argtypes = [vp, vp, dp, ctypes.c_int, vp, vp]
         L.mi_diis_dots.argtypes = [vp, vp, vp, ctypes.c_int, dp, vp]
         L.mi_diis_dots_dev.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp]
+        L.mi_diis_solve.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]
+        L.mi_diis_combine_dev.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp]
         i64 = ctypes.c_int64
         L.mi_grid_becke.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         L.mi_eval_ao.argtypes = [vp, vp, i64, ctypes.c_int, vp, vp]
@@ -88,7 +90,7 @@ def lib():
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_sp2_iterate.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, ctypes.POINTER(vp), vp]
         L.mi_sp2_iterate_pingpong.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
-        L.mi_sp2_iterate_planned.argtypes = [vp, vp, vp, vp, ctypes.c_int, dp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
+        L.mi_sp2_iterate_planned.argtypes = [vp, vp, vp, vp, ctypes.c_int, dp, ctypes.c_double, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
         L.mi_grad_1e.argtypes = [vp, vp, vp, vp, vp]
         L.mi_grad_eri.argtypes = [vp, vp, ctypes.c_double, vp, vp]
         L.mi_grad_eri_spin.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
@@ -414,14 +416,14 @@ class Engine:
         """Number of fixed-order partial sums `fock_energy` / `commutator_norm` write (ceil(nao^2 / 256))."""
         return (self.nao * self.nao + 255) // 256
 
-    def sp2_iterate_planned(self, F, A, B, coef, tr):
+    def sp2_iterate_planned(self, F, A, B, coef, tr, out_scale=1.0):
         """Planned purification (`sp2plan.plan` coefficients [nit+1, 3]) of the orthonormal-basis Fock matrix F on two
         [X|X2] buffers: returns (result buffer, offset in `tr` of the last pass's partial traces)."""
         coef = np.ascontiguousarray(coef, dtype=np.float64)
         nit = coef.shape[0] - 1
         out, res = ctypes.c_void_p(), ctypes.c_void_p()
-        _check(lib().mi_sp2_iterate_planned(self._h, F.data_ptr(), A.data_ptr(), B.data_ptr(), nit, _dp(coef), tr.data_ptr(),
-                                            ctypes.byref(out), ctypes.byref(res), self._stream()))
+        _check(lib().mi_sp2_iterate_planned(self._h, F.data_ptr(), A.data_ptr(), B.data_ptr(), nit, _dp(coef), float(out_scale),
+                                            tr.data_ptr(), ctypes.byref(out), ctypes.byref(res), self._stream()))
         return (A if res.value == A.data_ptr() else B), (out.value - tr.data_ptr()) // 8
 
     def fock_energy(self, h, J, K, Vxc, D, kscale, F, part):
@@ -445,6 +447,13 @@ class Engine:
 
     def diis_dots_dev(self, hist_e, e, n, out):
         _check(lib().mi_diis_dots_dev(self._h, hist_e.data_ptr(), e.data_ptr(), n, out.data_ptr(), self._stream()))
+
+    def diis_solve(self, part, m, slot, space, B, coef):
+        """Pulay system of the m stored vectors solved on the device (B, coef: device tensors [space,space], [space])."""
+        _check(lib().mi_diis_solve(self._h, part.data_ptr(), m, slot, space, B.data_ptr(), coef.data_ptr(), self._stream()))
+
+    def diis_combine_dev(self, hist, coef, n, out):
+        _check(lib().mi_diis_combine_dev(self._h, hist.data_ptr(), coef.data_ptr(), n, out.data_ptr(), self._stream()))
 
     def diis_dots(self, hist_e, e, n):
         out = np.zeros(n)

@@ -47,21 +47,29 @@ class DeviceDIIS:
         self.B = np.zeros((space, space))
         self._e = torch.empty(n, n, dtype=torch.float64, device=eng.device)
 
-    # --- split form used by the SCF step: `push` (device only, no sync) then `extrapolate` (host solve) ---
+    # --- split form used by the SCF step: `push*` (error-vector Gram row + Pulay solve, all on the device, no sync) then
+    # `extrapolate` (combination with the device-resident coefficients): no host round trip inside a cycle ---
+    NS = 16   # partial sums per Gram-row entry (DIIS_NS of the kernel), added in index order by the solve kernel
+
+    def _gram_and_solve(self, slot, m):
+        if not hasattr(self, "dots_dev"):
+            dev = self.F.device
+            self.dots_dev = torch.zeros(self.space * self.NS, dtype=torch.float64, device=dev)
+            self.B_dev = torch.zeros(self.space, self.space, dtype=torch.float64, device=dev)
+            self.coef_dev = torch.zeros(self.space, dtype=torch.float64, device=dev)
+        self.eng.diis_dots_dev(self.E, self.E[slot], m, self.dots_dev)
+        self.eng.diis_solve(self.dots_dev, m, slot, self.space, self.B_dev, self.coef_dev)
+        self._pending = (slot, m)
+
     def push(self, f, e):
-        """Store (F_i, e_i); leaves the new Gram row <e_j, e_i> in `self.dots_dev[:m]` on the device."""
+        """Store (F_i, e_i); leaves the Pulay coefficients of the enlarged history in `self.coef_dev[:m]` on the device."""
         slot = self.count % self.space
         self.F[slot].copy_(f)
         self.E[slot].copy_(e)
         self.count += 1
         m = min(self.count, self.space)
-        if not hasattr(self, "dots_dev"):
-            self.dots_dev = torch.zeros(self.space * self.NS, dtype=torch.float64, device=f.device)
-        self.eng.diis_dots_dev(self.E, self.E[slot], m, self.dots_dev)
-        self._pending = (slot, m)
+        self._gram_and_solve(slot, m)
         return m
-
-    NS = 16   # partial sums per Gram-row entry (DIIS_NS of the kernel): added on the host in index order
 
     def next_slot(self):
         """History slot the next push will use: the SCF step lets its GEMMs write F' and e straight into it."""
@@ -72,28 +80,15 @@ class DeviceDIIS:
         slot = self.count % self.space
         self.count += 1
         m = min(self.count, self.space)
-        if not hasattr(self, "dots_dev"):
-            self.dots_dev = torch.zeros(self.space * self.NS, dtype=torch.float64, device=self.F.device)
-        self.eng.diis_dots_dev(self.E, self.E[slot], m, self.dots_dev)
-        self._pending = (slot, m)
+        self._gram_and_solve(slot, m)
         return m
 
-    def extrapolate(self, dots):
-        slot, m = self._pending
-        dots = np.asarray(dots, dtype=np.float64)[:m * self.NS].reshape(m, self.NS).sum(axis=1)
-        self.B[slot, :m] = dots
-        self.B[:m, slot] = dots
-        A = np.zeros((m + 1, m + 1))
-        A[0, 1:] = A[1:, 0] = 1.0
-        A[1:, 1:] = self.B[:m, :m]
-        rhs = np.zeros(m + 1)
-        rhs[0] = 1.0
-        try:
-            c = np.linalg.solve(A, rhs)
-        except np.linalg.LinAlgError:
-            c = np.linalg.lstsq(A, rhs, rcond=None)[0]
+    def extrapolate(self, dots=None):
+        """F = sum_i c_i F_i with the coefficients the last push solved for (`dots` is ignored: kept for callers of the
+        round-1 host-solve signature)."""
+        _slot, m = self._pending
         out = torch.empty_like(self.F[0])
-        self.eng.diis_combine(self.F, c[1:], out)
+        self.eng.diis_combine_dev(self.F, self.coef_dev, m, out)
         return out
 
     def update(self, s, d, f):
@@ -463,23 +458,23 @@ class SCF:
         torch.matmul(X, X, out=X2)
         return 2.0 * X, torch.stack([torch.trace(X), torch.trace(X2)])
 
+    _HEAD_MAX = 4096   # doubles reserved in front of the planned-path trace history for [E partials | |g|^2 partials | extra]
+
     def _sp2_planned_async(self, fo, nocc):
-        """Planned purification, no host sync: (D', partial traces of every pass) -- validated by the caller like the
-        optimistic SP2 path."""
+        """Planned purification, no host sync: (D' = 2 X, partial traces of every pass) -- validated by the caller like the
+        optimistic SP2 path.  The traces land behind `_HEAD_MAX` doubles of one persistent buffer whose head the Fock build
+        fills afterwards, so the cycle's scalars leave the device as ONE contiguous copy without a gather kernel."""
         eng = self.engine
         n = fo.shape[0]
-        ws = getattr(self, "_sp2f", None)
-        if ws is None or ws["X"].shape[0] != n:
+        ws = getattr(self, "_sp2p", None)
+        if ws is None or ws["n"] != n:
             mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
-            ws = self._sp2f = dict(X=mk(n, n), X2=mk(n, n), work=mk(2 * n * n), tr=mk(64 * 80), b=mk(2 * n))
-        pp = ws.get("pp")
-        if pp is None:
-            pp = ws["pp"] = (torch.empty(2, n, n, dtype=torch.float64, device=fo.device),
-                             torch.empty(2, n, n, dtype=torch.float64, device=fo.device))
+            ws = self._sp2p = dict(n=n, scal=mk(self._HEAD_MAX + 64 * 80), pp=(mk(2, n, n), mk(2, n, n)))
         coef = self._sp2_plan[:self._sp2_plan_len + 1]
-        res, off = eng.sp2_iterate_planned(fo.contiguous(), pp[0], pp[1], coef, ws["tr"])
+        tr = ws["scal"][self._HEAD_MAX:]
+        res, off = eng.sp2_iterate_planned(fo.contiguous(), ws["pp"][0], ws["pp"][1], coef, tr, out_scale=2.0)
         self._sp2_hist_shape = (coef.shape[0], (n + 15) // 16)
-        return 2.0 * res[0], ws["tr"][:off + 64]
+        return res[0], tr[:off + 64]   # a view of the ping-pong buffers: consumed by this cycle's Fock build, before the next pass
 
     def _sp2_replan(self, mo_e, nocc):
         """New plan from the eigenvalues of the (orthonormal-basis) Fock matrix just diagonalised."""
@@ -555,14 +550,30 @@ class SCF:
         self._after_density(st, dm, e_last=None, next_cycle=0)
         return st
 
-    def _after_density(self, st, dm, e_last, next_cycle, sp2_tr=None, nocc=0):
+    def _after_density(self, st, dm, e_last, next_cycle, sp2_tr=None, nocc=0, hist_shape=None):
         """J/K(+XC) for `dm`, new Fock in the orthonormal basis, commutator error, energy, |g|; pushes
         (F', e) into the DIIS history and fetches all scalars of the cycle with ONE device-to-host copy."""
-        Li, L, h1 = self._Linv, self._L, self._h1
+        ctx = self._after_density_launch(st, dm, next_cycle, sp2_tr, hist_shape)
+        return self._after_density_finish(st, ctx, e_last, nocc)
+
+    _PIN_DOUBLES = 16384
+
+    def _after_density_launch(self, st, dm, next_cycle, sp2_tr=None, hist_shape=None):
+        """Device part of `_after_density`: everything is queued, the scalars of the cycle are on their way to pinned host
+        memory (asynchronous copy + event) when this returns -- the caller may queue more work before `_after_density_finish`
+        waits for them."""
+        Li, L = self._Linv, self._L
         dm = dm.contiguous()
         nb = self.engine.reduce_blocks
         self.n_fock_builds = getattr(self, "n_fock_builds", 0) + 1
-        part = torch.empty(2 * nb, dtype=torch.float64, device=dm.device)   # partial sums of [E_elec | |[F',D']|^2]
+        # partial sums of [E_elec | |[F',D']|^2]: on the planned path they go right in front of the trace history
+        ws = getattr(self, "_sp2p", None)
+        inplace = (sp2_tr is not None and ws is not None and 2 * nb <= self._HEAD_MAX
+                   and sp2_tr.data_ptr() == ws["scal"].data_ptr() + 8 * self._HEAD_MAX)
+        if inplace:
+            part = ws["scal"][self._HEAD_MAX - 2 * nb:self._HEAD_MAX]
+        else:
+            part = torch.empty(2 * nb, dtype=torch.float64, device=dm.device)
         fock, extra = self._fock_energy(dm, part[:nb])
         # PySCF feeds CDIIS only from cycle `diis_start_cycle` on [MEM]: the initial-guess Fock is not stored.  When it is
         # stored, the two GEMM chains write F' and the error vector straight into the history slot (no device copies).
@@ -573,35 +584,53 @@ class SCF:
         m = fo @ st["dmo"]
         eo = torch.empty_like(m)
         self.engine.commutator_norm(m, eo, part[nb:])  # eo = [F', D'] and the partial sums of its squared norm
-        # e_ao = F D S - S D F = L [F', D'] L^T  (PySCF's CDIIS error vector [MEM])
+        # e_ao = F D S - S D F = L [F', D'] L^T  (PySCF's CDIIS error vector [MEM]); the push also solves the Pulay system
+        # on the device, so the next cycle's extrapolation needs nothing from the host
         if keep:
             torch.matmul(L @ eo, L.T, out=diis.E[slot])
-            nd = diis.push_inplace()
+            diis.push_inplace()
+        if inplace and extra is None:
+            packed = ws["scal"][self._HEAD_MAX - 2 * nb:self._HEAD_MAX + sp2_tr.numel()]   # already contiguous: no gather kernel
         else:
-            nd = 0
-        n = fo.shape[0]
-        nvo = max((n - st["nocc"]) * st["nocc"], 1)
-        ndp = nd * DeviceDIIS.NS
-        parts = ([st["diis"].dots_dev[:ndp]] if nd else []) + [part] + ([extra.reshape(1)] if extra is not None else []) \
-            + ([sp2_tr] if sp2_tr is not None else [])
-        packed = torch.cat(parts) if len(parts) > 1 else part
+            parts = [part] + ([extra.reshape(1)] if extra is not None else []) + ([sp2_tr] if sp2_tr is not None else [])
+            packed = torch.cat(parts) if len(parts) > 1 else part
         # Sharded runs: every rank holds the same all-reduced J/K(/Vxc) and the replicated algebra above is free of atomics
         # (fixed-order partial sums), so these scalars are bit-identical on all ranks and steer identical control flow --
         # no broadcast.  `sync_control = True` restores the round-1 broadcast of rank 0's copy (debugging aid).
         if self._nranks > 1 and self.sync_control:
             from . import parallel
             parallel.broadcast0(packed, self._pg)
-        vals = packed.cpu().numpy()                    # the cycle's only host sync
-        pos = ndp
-        e_el = float(vals[pos:pos + nb].sum())         # numpy's pairwise sum: the same order on every rank
-        c2 = float(vals[pos + nb:pos + 2 * nb].sum())
-        pos += 2 * nb
-        if extra is not None:
+        ctx = dict(dm=dm, fock=fock, fo=fo, nb=nb, has_extra=extra is not None, has_tr=sp2_tr is not None, hist_shape=hist_shape,
+                   packed=packed, event=None)
+        k = packed.numel()
+        if k <= self._PIN_DOUBLES:
+            pin = getattr(self, "_pin", None)
+            if pin is None:
+                pin = self._pin = torch.empty(self._PIN_DOUBLES, dtype=torch.float64).pin_memory()
+                self._pin_event = torch.cuda.Event()
+            pin[:k].copy_(packed, non_blocking=True)
+            self._pin_event.record()
+            ctx["event"] = self._pin_event
+        return ctx
+
+    def _after_density_finish(self, st, ctx, e_last, nocc=0):
+        """Host part: wait for the scalars of the cycle (the only host synchronisation of a cycle), validate the optimistic
+        purification, update the state.  False: the purification had not converged -- nothing in `st` was touched."""
+        nb = ctx["nb"]
+        if ctx["event"] is not None:
+            ctx["event"].synchronize()
+            vals = self._pin[:ctx["packed"].numel()].numpy().copy()
+        else:
+            vals = ctx["packed"].cpu().numpy()
+        e_el = float(vals[:nb].sum())                  # numpy's pairwise sum: the same order on every rank
+        c2 = float(vals[nb:2 * nb].sum())
+        pos = 2 * nb
+        if ctx["has_extra"]:
             e_el += float(vals[pos])
             pos += 1
-        if sp2_tr is not None:
+        if ctx["has_tr"]:
             hist = vals[pos:]
-            shape = getattr(self, "_sp2_hist_shape", None)
+            shape = ctx["hist_shape"]
             if shape is not None and hist.size == shape[0] * 64:
                 h = hist.reshape(shape[0], 32, 2)[:, :shape[1], :]
                 tx, tx2 = h[:, :, 0].sum(axis=1), h[:, :, 1].sum(axis=1)     # per step, partials added in index order
@@ -617,59 +646,93 @@ class SCF:
                 trx, trx2 = self._sp2_traces(hist)
                 if not (abs(trx - trx2) < self.sp2_tol and abs(trx - nocc) < 1e-8):
                     return False
-            self._sp2_hist_shape = None
         e_tot = e_el + st["enuc"]
+        n = ctx["fo"].shape[0]
+        nvo = max((n - st["nocc"]) * st["nocc"], 1)
         # |g| = |2 F_vo| = |[F',D']|_F / sqrt(2), normalised by sqrt(n_vo) like PySCF's get_grad norm [MEM]
         gnorm = float(np.sqrt(max(c2, 0.0))) / np.sqrt(2.0) / np.sqrt(nvo)
-        st.update(dm=dm, fock=fock, fo=fo, dots=vals[:ndp], e_tot=e_tot, gnorm=gnorm,
+        st.update(dm=ctx["dm"], fock=ctx["fock"], fo=ctx["fo"], e_tot=e_tot, gnorm=gnorm,
                   de=(e_tot - e_last) if e_last is not None else 0.0)
         return True
 
+    pipeline = True   # queue the device-only head of cycle k+1 (extrapolation, purification, density) before waiting for cycle k's scalars
+
+    def _front(self, st):
+        """Device-only head of the NEXT cycle, queued speculatively: CDIIS-extrapolated F' (coefficients solved on the device)
+        -> planned purification -> AO density.  The GPU works on it while the host reads back and checks the scalars of the
+        cycle that just finished; the caller drops it when that cycle turns out converged or invalid.  None when the next
+        cycle cannot take the planned path."""
+        nocc = st["nocc"]
+        n = self._Linv.shape[0]
+        if not (self.pipeline and self.eig_method == "sp2" and self.sp2_planned and self.sp2_fused and n <= self.sp2_fused_max
+                and 0 < nocc < n and not self.level_shift and self._sp2_plan is not None
+                and st["cycle"] + 1 >= self.diis_start_cycle and st["diis"].count > 0):
+            return None
+        fo = st["diis"].extrapolate()
+        dmo, tr_dev = self._sp2_planned_async(fo, nocc)
+        shape, self._sp2_hist_shape = self._sp2_hist_shape, None
+        dm = (self._Linv.T @ dmo @ self._Linv).contiguous()
+        return dict(fo=fo, dmo=dmo, dm=dm, tr=tr_dev, shape=shape)
+
     def _step(self, st, use_diis=True, want_mo=False):
         """One SCF cycle: CDIIS extrapolation -> occupied projector (SP2 or eigh) -> density -> J/K ->
-        energy, orbital gradient.  This is the unit bench.py times ("SCF iteration")."""
+        energy, orbital gradient.  This is the unit bench.py times ("SCF iteration").  With `pipeline` the first three
+        stages of a cycle are queued on the device by the PREVIOUS call, before it waited for its own scalars."""
         nocc, Li = st["nocc"], self._Linv
-        if use_diis and st["cycle"] >= self.diis_start_cycle:
-            fo = st["diis"].extrapolate(st["dots"])
-        else:
-            fo = st["fo"]
-        if self.level_shift and use_diis:
-            # PySCF `level_shift`: raise the virtual space of the matrix the new orbitals come from, F' + s (1 - D'/2), D' the
-            # current projector x 2; it leaves a converged solution unchanged and is not applied to the final (extra) cycle
-            fo = fo + self.level_shift * (torch.eye(fo.shape[0], dtype=fo.dtype, device=fo.device) - 0.5 * st["dmo"])
-        tr_dev = None
-        use_sp2 = self.eig_method == "sp2" and not want_mo
-        n = fo.shape[0]
-        planned_ok = (use_sp2 and self.sp2_planned and self.sp2_fused and n <= self.sp2_fused_max and 0 < nocc < n
-                      and not self.level_shift)
+        front = st.pop("front", None)
+        if want_mo or not use_diis:
+            front = None                                 # final cycle: plain diagonalisation of the last Fock matrix
+        tr_dev, hist_shape = None, None
         self._sp2_planned_pass = False
-        dmo = None
-        if planned_ok and self._sp2_plan is not None and not st.get("_redo"):
-            dmo, tr_dev = self._sp2_planned_async(fo, nocc)
+        if front is not None:
+            fo, dmo, tr_dev, hist_shape, dm = front["fo"], front["dmo"], front["tr"], front["shape"], front["dm"]
             self._sp2_planned_pass = True
-        elif planned_ok:
-            pass                                     # no plan yet: diagonalise below, which also yields the bounds for one
-        elif use_sp2 and self._sp2_validated and 0 < nocc < n and not st.get("_redo"):
-            dmo, tr_dev = self._sp2_fused_async(fo, nocc)
-        elif use_sp2:
-            dmo = self._density_sp2(fo, nocc, orth=True)
-        if dmo is None:
-            e, c = torch.linalg.eigh(fo)
-            co = c[:, :nocc]
-            dmo = 2.0 * co @ co.T
-            st.update(mo_e=e, mo_c=Li.T @ c)
-            if planned_ok:
-                self._sp2_replan(e, nocc)
-        else:
+            planned_ok = True
             st.pop("mo_e", None)
+        else:
+            if use_diis and st["cycle"] >= self.diis_start_cycle:
+                fo = st["diis"].extrapolate()
+            else:
+                fo = st["fo"]
+            if self.level_shift and use_diis:
+                # PySCF `level_shift`: raise the virtual space of the matrix the new orbitals come from, F' + s (1 - D'/2), D' the
+                # current projector x 2; it leaves a converged solution unchanged and is not applied to the final (extra) cycle
+                fo = fo + self.level_shift * (torch.eye(fo.shape[0], dtype=fo.dtype, device=fo.device) - 0.5 * st["dmo"])
+            use_sp2 = self.eig_method == "sp2" and not want_mo
+            n = fo.shape[0]
+            planned_ok = (use_sp2 and self.sp2_planned and self.sp2_fused and n <= self.sp2_fused_max and 0 < nocc < n
+                          and not self.level_shift)
+            dmo = None
+            if planned_ok and self._sp2_plan is not None and not st.get("_redo"):
+                dmo, tr_dev = self._sp2_planned_async(fo, nocc)
+                self._sp2_planned_pass = True
+            elif planned_ok:
+                pass                                     # no plan yet: diagonalise below, which also yields the bounds for one
+            elif use_sp2 and self._sp2_validated and 0 < nocc < n and not st.get("_redo"):
+                dmo, tr_dev = self._sp2_fused_async(fo, nocc)
+            elif use_sp2:
+                dmo = self._density_sp2(fo, nocc, orth=True)
+            hist_shape, self._sp2_hist_shape = getattr(self, "_sp2_hist_shape", None), None
+            if dmo is None:
+                e, c = torch.linalg.eigh(fo)
+                co = c[:, :nocc]
+                dmo = 2.0 * co @ co.T
+                st.update(mo_e=e, mo_c=Li.T @ c)
+                if planned_ok:
+                    self._sp2_replan(e, nocc)
+            else:
+                st.pop("mo_e", None)
+            dm = Li.T @ dmo @ Li
         saved = (st["dmo"], st["diis"].count) if tr_dev is not None else None
         st["dmo"] = dmo
-        dm = Li.T @ dmo @ Li
         e_prev = st["e_tot"]
-        ok = self._after_density(st, dm, e_last=e_prev, next_cycle=st["cycle"] + 1, sp2_tr=tr_dev, nocc=nocc)
+        ctx = self._after_density_launch(st, dm, st["cycle"] + 1, sp2_tr=tr_dev, hist_shape=hist_shape)
+        nxt = self._front(st) if (use_diis and not want_mo) else None
+        ok = self._after_density_finish(st, ctx, e_prev, nocc)
         if not ok:
             # the optimistic purification had not converged (planned path: the spectrum left the planned bounds): roll the DIIS
             # push back and redo this cycle -- planned path by diagonalisation (fresh bounds), otherwise by the checked SP2
+            nxt = None
             st["dmo"], st["diis"].count = saved
             st["e_tot"] = e_prev
             self._sp2_validated = False
@@ -686,6 +749,8 @@ class SCF:
                 self._after_density(st, Li.T @ dmo @ Li, e_last=e_prev, next_cycle=st["cycle"] + 1)
             finally:
                 st.pop("_redo", None)
+        if nxt is not None:
+            st["front"] = nxt
         st["cycle"] += 1
         return st
 
@@ -704,6 +769,7 @@ class SCF:
             if abs(st["de"]) < conv_tol and st["gnorm"] < conv_tol_grad:
                 self.converged = True
                 break
+        st.pop("front", None)                            # the speculative head of a cycle that will not run
         self.cycles = st["cycle"]
         self.timing["loop_seconds"] = time.time() - t_loop
         if self.converged and self.conv_check:

@@ -137,6 +137,13 @@ int mi_diis_dots(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int n, 
  * the energy and the gradient norm with ONE device-to-host copy. */
 int mi_diis_dots_dev(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int n, double *d_out,
                      void *stream);
+/* Round 2: the Pulay solve itself on the device, so that a cycle's extrapolation needs no host round trip (scf.diis.CDIIS ->
+ * lib.diis.DIIS.extrapolate: numpy.linalg.solve of the (m+1)x(m+1) B-matrix system).  d_part = the [m][16] partials
+ * mi_diis_dots_dev just wrote for the error vector in history slot `slot`; d_B [space][space] is the device-resident Gram
+ * matrix (row/column `slot` are replaced), d_coef[0..m) receives the coefficients (no extrapolation, c = e_slot, when the
+ * system is singular).  mi_diis_combine_dev = mi_diis_combine with the coefficients read from device memory. */
+int mi_diis_solve(mi_ctx *ctx, const double *d_part, int m, int slot, int space, double *d_B, double *d_coef, void *stream);
+int mi_diis_combine_dev(mi_ctx *ctx, const double *d_hist, const double *d_coef, int n, double *d_out, void *stream);
 
 
 /* ---- density from the Fock matrix without diagonalisation (row a11) ----------------------------- */
@@ -163,9 +170,11 @@ int mi_sp2_iterate_pingpong(mi_ctx *ctx, double *d_A, double *d_B, int nit, doub
 /* Planned purification: the whole sequence of quadratics is fixed by the caller from bounds of the spectrum (outer) and of
  * the HOMO / LUMO (inner) -- see mi355scf/sp2plan.py.  coef[3*(nit+1)]: pass 0 forms X_0 = coef[1] F + coef[2] I from the
  * (orthonormal-basis) Fock matrix d_F, pass k applies X_k = coef[3k] X^2 + coef[3k+1] X + coef[3k+2] I.  Buffers and trace
- * output as in mi_sp2_iterate_pingpong (the caller validates tr(X - X^2) and tr X of the last pass). */
-int mi_sp2_iterate_planned(mi_ctx *ctx, const double *d_F, double *d_A, double *d_B, int nit, const double *coef, double *d_tr,
-                           double **d_tr_out, double **d_res, void *stream);
+ * output as in mi_sp2_iterate_pingpong (the caller validates tr(X - X^2) and tr X of the last pass).  The stored result of
+ * the LAST pass is out_scale * X (2 = closed-shell density matrix in the orthonormal basis; 0 or 1 = the projector itself);
+ * the traces are always those of the unscaled X. */
+int mi_sp2_iterate_planned(mi_ctx *ctx, const double *d_F, double *d_A, double *d_B, int nit, const double *coef, double out_scale,
+                           double *d_tr, double **d_tr_out, double **d_res, void *stream);
 
 /* Fused elementwise pieces of one SCF cycle (rows a11/a12: get_fock + energy_elec, orbital-gradient norm):
  * mi_fock_energy: F = h + J - kscale*K (+Vxc); d_part[b] = block b's share of sum D*(h + (J - kscale*K)/2).  d_K, d_Vxc may be NULL.
