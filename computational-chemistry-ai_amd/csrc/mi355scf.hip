@@ -2848,64 +2848,94 @@ extern "C" int mi_diis_dots_dev(mi_ctx *c, const double *d_hist_e, const double 
 // vectors exactly zero) falls back to c = e_slot, i.e. no extrapolation.  Same instruction sequence on every rank of a
 // sharded run, so the coefficients are bit-identical there.
 #define DIIS_MAXM 16
-__global__ __launch_bounds__(64) void diis_solve_kernel(const double *part, int m, int slot, int space, double *B, double *coef)
+// value of `x` on lane `l` (wave-uniform l) through v_readlane: no LDS crossbar trip, unlike __shfl with a runtime lane
+__device__ __forceinline__ double lane_bcast(double x, int l)
 {
-    __shared__ double A[DIIS_MAXM + 1][DIIS_MAXM + 2];
+    const int ls = __builtin_amdgcn_readfirstlane(l);
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), ls);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), ls);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// One wave, no LDS, no barriers: lane r owns row r of the augmented system in registers, pivot search and row broadcasts are
+// wave shuffles (the first version -- rows in LDS, lane 0 searching the pivot -- took 14 us, mostly serial LDS latency).
+__global__ __launch_bounds__(64) void diis_solve_kernel(const double *__restrict__ part, int m, int slot, int space, double *B, double *__restrict__ coef)
+{
     const int t = threadIdx.x;
-    if (t < m) {
-        double s = 0.0;
-        for (int q = 0; q < DIIS_NS; q++) s += part[t * DIIS_NS + q];
-        B[slot * space + t] = s;
-        B[t * space + slot] = s;
-    }
-    __syncthreads();
     const int n = m + 1;
-    for (int idx = t; idx < n * (n + 1); idx += 64) {
-        const int i = idx / (n + 1), j = idx - i * (n + 1);
-        double v;
-        if (j == n) v = (i == 0) ? 1.0 : 0.0;
-        else if (i == 0) v = (j == 0) ? 0.0 : 1.0;
-        else if (j == 0) v = 1.0;
-        else v = B[(i - 1) * space + (j - 1)];
-        A[i][j] = v;
+    double dot = 0.0;                         // lane i < m: <e_i, e_slot>
+    double bold[DIIS_MAXM];                   // the older Gram entries of this lane's row: requested before anything waits
+#pragma unroll
+    for (int j = 0; j < DIIS_MAXM; j++) bold[j] = (t >= 1 && t <= m && j < m) ? B[(t - 1) * space + j] : 0.0;
+    if (t < m) {
+        double pq[DIIS_NS];
+#pragma unroll
+        for (int q = 0; q < DIIS_NS; q++) pq[q] = part[t * DIIS_NS + q];   // 16 independent loads in flight, then the ordered sum
+#pragma unroll
+        for (int q = 0; q < DIIS_NS; q++) dot += pq[q];
+        B[slot * space + t] = dot;
+        B[t * space + slot] = dot;
     }
-    __syncthreads();
-    // elimination with the rows spread over the lanes (lane i owns row i): 9 short steps instead of a serial triple loop
-    __shared__ int piv_s;
-    __shared__ int ok_s;
-    if (t == 0) ok_s = 1;
-    __syncthreads();
-    for (int k = 0; k < n; k++) {
-        if (t == 0) {
+    const double dot_row = __shfl(dot, t > 0 ? t - 1 : 0);   // <e_{r-1}, e_slot> for the lane that owns row r
+    double a[DIIS_MAXM + 1];                  // columns 0..n-1 of row t (compile-time indices only: stays in registers)
+    double rhs = (t == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j <= DIIS_MAXM; j++) {
+        const double dot_col = __shfl(dot, j > 0 ? j - 1 : 0);
+        double v = 0.0;
+        if (t < n && j < n) {
+            if (t == 0) v = (j == 0) ? 0.0 : 1.0;
+            else if (j == 0) v = 1.0;
+            else if (t - 1 == slot) v = dot_col;
+            else if (j - 1 == slot) v = dot_row;
+            else v = bold[j - 1];                         // older entries: not written by this launch
+        }
+        a[j] = v;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k <= DIIS_MAXM; k++) {
+        if (k < n && ok) {
+            // pivot: largest |a[r][k]|, r = k .. n-1 (first one on ties); rows are lanes, so this is a scalar scan of lane reads
+            const double mine = fabs(a[k]);
+            double val = -1.0;
             int p = k;
-            double big = fabs(A[k][k]);
-            for (int i = k + 1; i < n; i++) if (fabs(A[i][k]) > big) { big = fabs(A[i][k]); p = i; }
-            if (!(big > 0.0) || !isfinite(big)) ok_s = 0;
-            piv_s = p;
-        }
-        __syncthreads();
-        if (!ok_s) break;
-        const int p = piv_s;
-        if (p != k && t <= n) { double tmp = A[k][t]; A[k][t] = A[p][t]; A[p][t] = tmp; }   // lane t swaps column t of the two rows
-        __syncthreads();
-        if (t > k && t < n) {
-            const double f = A[t][k] / A[k][k];
-            if (f != 0.0) for (int j = k; j <= n; j++) A[t][j] -= f * A[k][j];
-        }
-        __syncthreads();
-    }
-    if (t != 0) return;
-    bool ok = ok_s != 0;
-    double x[DIIS_MAXM + 1];
-    if (ok) {
-        for (int i = n - 1; i >= 0; i--) {
-            double sx = A[i][n];
-            for (int j = i + 1; j < n; j++) sx -= A[i][j] * x[j];
-            x[i] = sx / A[i][i];
-            if (!isfinite(x[i])) ok = false;
+#pragma unroll
+            for (int r = 0; r <= DIIS_MAXM; r++) {
+                if (r >= k && r < n) {
+                    const double v = lane_bcast(mine, r);
+                    if (v > val) { val = v; p = r; }
+                }
+            }
+            if (!(val > 0.0) || !isfinite(val)) ok = false;   // wave-uniform
+            const bool below = t > k && t < n;
+            double f = 0.0;
+#pragma unroll
+            for (int j = 0; j <= DIIS_MAXM; j++) {
+                if (j >= k && j < n) {
+                    const double rk = lane_bcast(a[j], k), rp = lane_bcast(a[j], p);
+                    if (t == k) a[j] = rp; else if (t == p) a[j] = rk;     // rows k and p change places
+                    if (j == k) f = below ? a[k] / rp : 0.0;
+                    if (below) a[j] -= f * rp;                             // (a[k] itself becomes 0)
+                }
+            }
+            const double rk = lane_bcast(rhs, k), rp = lane_bcast(rhs, p);
+            if (t == k) rhs = rp; else if (t == p) rhs = rk;
+            if (below) rhs -= f * rp;
         }
     }
-    for (int i = 0; i < m; i++) coef[i] = ok ? x[i + 1] : (i == slot ? 1.0 : 0.0);
+    double acc = 0.0, myx = 0.0;
+#pragma unroll
+    for (int i = DIIS_MAXM; i >= 0; i--) {
+        if (i < n) {
+            const double cand = (rhs - acc) / a[i];   // meaningful on lane i only
+            const double xi = lane_bcast(cand, i);
+            if (!isfinite(xi)) ok = false;
+            if (t == i) myx = xi;
+            acc += a[i] * xi;
+        }
+    }
+    if (t >= 1 && t <= m) coef[t - 1] = ok ? myx : ((t - 1) == slot ? 1.0 : 0.0);
 }
 
 extern "C" int mi_diis_solve(mi_ctx *c, const double *d_part, int m, int slot, int space, double *d_B, double *d_coef, void *stream)

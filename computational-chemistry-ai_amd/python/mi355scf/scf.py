@@ -534,8 +534,8 @@ class SCF:
     # --- the SCF loop (row a12) -----------------------------------------------------------------
     def _start(self, dm0=None):
         """Prepare integrals/ERIs and the iteration state.  The loop works in the Cholesky-orthogonalised
-        basis (F' = L^-1 F L^-T, D' = L^T D L); the DIIS error vector is PySCF's AO-basis FDS - SDF =
-        L (F'D' - D'F') L^T, so the extrapolation path is the reference one."""
+        basis (F' = L^-1 F L^-T, D' = L^T D L); the DIIS error vector is PySCF's orthonormal-basis C^T (SDF - FDS) C, whose Gram
+        matrix equals that of [F', D'], so the extrapolation path is the reference one."""
         mol = self.mol
         self._setup_once()
         eng = self.engine
@@ -582,12 +582,15 @@ class SCF:
         slot = diis.next_slot()
         fo = torch.matmul(Li @ fock, Li.T, out=diis.F[slot]) if keep else Li @ fock @ Li.T
         m = fo @ st["dmo"]
-        eo = torch.empty_like(m)
+        # CDIIS error vector in an ORTHONORMAL basis, as PySCF >= 2.1 forms it (scf/diis.py get_err_vec_orth: C^T (SDF - FDS) C
+        # with C = `Corth`, the eigenvectors of the first Fock matrix [MEM; the reference pins pyscf 2.8.0]).  With the Cholesky
+        # basis X = L^-T instead of C, X^T (SDF - FDS) X = D'F' - F'D' = -[F', D']; the two orthonormal bases differ by an
+        # orthogonal matrix, which leaves every <e_i, e_j> -- all that the Pulay system sees -- unchanged.  So the commutator
+        # IS the error vector: it is written straight into the history slot (round 1 transformed it to the AO basis, the
+        # pre-2.1 definition, with two more GEMMs).  The push also solves the Pulay system on the device.
+        eo = diis.E[slot] if keep else torch.empty_like(m)
         self.engine.commutator_norm(m, eo, part[nb:])  # eo = [F', D'] and the partial sums of its squared norm
-        # e_ao = F D S - S D F = L [F', D'] L^T  (PySCF's CDIIS error vector [MEM]); the push also solves the Pulay system
-        # on the device, so the next cycle's extrapolation needs nothing from the host
         if keep:
-            torch.matmul(L @ eo, L.T, out=diis.E[slot])
             diis.push_inplace()
         if inplace and extra is None:
             packed = ws["scal"][self._HEAD_MAX - 2 * nb:self._HEAD_MAX + sp2_tr.numel()]   # already contiguous: no gather kernel

@@ -128,15 +128,21 @@ class Oracle:
 # ------------------------------------------------------------------------------------------------
 
 class CDIIS:
-    """Pulay DIIS on e = SDF - FDS, subspace 8 (PySCF `scf.diis.CDIIS` defaults [MEM])."""
+    """Pulay DIIS, subspace 8 (PySCF `scf.diis.CDIIS` defaults [MEM]).  Error vector: with `Corth` set (what `SCF.kernel` of
+    PySCF >= 2.1 does: `_, mf_diis.Corth = mf.eig(fock, s1e)` on the first Fock matrix [MEM: pyscf 2.8 scf/hf.py, scf/diis.py
+    get_err_vec_orth]) e = Corth^T (SDF - FDS) Corth in that orthonormal basis; without it the older AO-basis SDF - FDS."""
 
-    def __init__(self, space=8):
+    def __init__(self, space=8, Corth=None):
         self.space = space
+        self.Corth = Corth
         self.f, self.e = [], []
 
     def update(self, s, d, f):
         sdf = s @ d @ f
-        err = (sdf.T - sdf).ravel()
+        err = sdf.T - sdf
+        if self.Corth is not None:
+            err = self.Corth.T @ err @ self.Corth
+        err = err.ravel()
         self.f.append(f.copy())
         self.e.append(err)
         if len(self.f) > self.space:
@@ -198,7 +204,7 @@ def rhf(mol, dm0=None, conv_tol=1e-9, max_cycle=50, veff_fn=None, verbose=False,
         dm = np.array(dm0, dtype=np.float64)
     vhf, exc = veff_fn(dm)
     e_tot = energy(dm, vhf, exc)
-    diis = CDIIS()
+    diis = CDIIS(Corth=eig_gen(h + vhf, S)[1])
     conv_tol_grad = np.sqrt(conv_tol)
     converged = False
     mo_e = mo_c = None
