@@ -99,6 +99,11 @@ class RKS(RHF):
         # grid block: as large as a ~1.5 GB working set allows (fewer launches for small molecules), at least grid_block
         B = max(self.grid_block, int(1.5e9 / (48.0 * n)) // 1024 * 1024)
         cache = self._ao_cache_for(n, hi - lo, 4 if gga else 1)
+        Zt = self._occ_factor(dm)
+        if Zt is not None:   # [nao, ldz] with the orbital index fastest, zero-padded to the kernel's chunk (24 GGA / 32 LDA)
+            ch = 24 if gga else 32
+            Zp = torch.zeros(n, (Zt.shape[0] + ch - 1) // ch * ch, dtype=torch.float64, device=Zt.device)
+            Zp[:, :Zt.shape[0]] = Zt.T
         for ib, p0 in enumerate(range(lo, hi, B)):
             p1 = min(p0 + B, hi)
             c, w = coords[p0:p1], weights[p0:p1]
@@ -108,10 +113,18 @@ class RKS(RHF):
                 ao = eng.eval_ao(c, deriv=1 if gga else 0)
                 if cache is not None:
                     cache.append(ao)
-            C = dm @ ao[0]
-            rho = eng.xc_rho(ao, C, deriv=1 if gga else 0)
+            if Zt is not None:
+                # D = Z Z^T: densities from the occupied orbitals on the grid (nao / n_occ times fewer flops and bytes than D.ao)
+                if gga == 2:
+                    rho, tau = eng.xc_rho_lowrank(ao, Zp, deriv=1, with_tau=True)
+                else:
+                    rho, tau = eng.xc_rho_lowrank(ao, Zp, deriv=1 if gga else 0), None
+            else:
+                C = dm @ ao[0]
+                rho = eng.xc_rho(ao, C, deriv=1 if gga else 0)
+                tau = eng.xc_tau(ao, dm) if gga == 2 else None
             if gga == 2:
-                e, wv = eng.xc_eval_mgga(terms, rho, eng.xc_tau(ao, dm), w)
+                e, wv = eng.xc_eval_mgga(terms, rho, tau, w)
             else:
                 e, wv = eng.xc_eval(terms, rho, w, gga)
             tail[0] += torch.dot(w, rho[0])
@@ -122,6 +135,41 @@ class RKS(RHF):
                 for k in (1, 2, 3):
                     eng.xc_vmat(ao[k], wv[4] * ao[k], vmat)
         return hyb
+
+    xc_lowrank = True   # inside the SCF loop: rho from occupied-orbital values (D = Z Z^T) instead of D.ao
+
+    def _occ_factor(self, dm):
+        """Z^T [n_occ, nao] with D = Z Z^T when the SCF step declared `dm` a closed-shell projector density (`_xc_projector`:
+        D' = 2 X in the orthonormal basis, X idempotent of rank n_occ), else None.  No diagonalisation: W = X G for a fixed
+        Gaussian G [nao, n_occ] spans the occupied space, M = G^T X G = W^T W, Cholesky M = R R^T, Z' = W R^-T has orthonormal
+        columns (X = Z' Z'^T), Z = sqrt(2) L^-T Z'.  cond(M) is that of a square Gaussian matrix squared (~1e3-1e4), so the
+        factorisation is accurate to ~1e-12 (PySCF's numint takes the same shortcut from mo_coeff / mo_occ [MEM: eval_rho2])."""
+        proj = getattr(self, "_xc_projector", None)
+        if not self.xc_lowrank or proj is None or proj[0] is not dm:
+            return None
+        _dm, dmo, nocc = proj
+        n = dmo.shape[0]
+        if not (0 < nocc < n // 2):
+            return None
+        G0 = getattr(self, "_nystrom_G0", None)
+        if G0 is None or G0.shape != (n, nocc) or G0.device != dmo.device:
+            g = torch.Generator(device="cpu").manual_seed(20251004)
+            G0 = self._nystrom_G0 = torch.randn(n, nocc, generator=g, dtype=torch.float64).to(dmo.device)
+            self._nystrom_G = G0
+        # test matrix: the previous cycle's orthonormal occupied basis plus 5 % of the fixed Gaussian one.  Near convergence
+        # X G ~ G, so M ~ 2 I and the factor is accurate to rounding (a pure Gaussian G gives cond(M) ~ 1e3-1e4, i.e. 1e-12
+        # relative noise in rho -- visible as 1e-10 Ha jitter in E_xc of a 650 Ha molecule converged to conv_tol = 1e-10);
+        # the Gaussian part keeps M non-singular when the occupied space has changed completely (new geometry, new state).
+        G = self._nystrom_G
+        W = dmo @ G                                        # = 2 X G
+        M = G.T @ W                                        # = 2 G^T X G
+        R, _info = torch.linalg.cholesky_ex(M)             # no host sync; a failed factorisation shows up as a wrong N_elec
+        Zp_t = torch.linalg.solve_triangular(R, W.T, upper=False)   # R^-1 W^T: rows orthogonal with norm^2 = 2 -> D' = Zp Zp^T
+        # (a cycle whose projector was not valid -- speculative purification, checked later by the host -- must not poison
+        # the warm start: keep the Gaussian matrix unless the factor is finite and the factorisation succeeded)
+        good = torch.isfinite(Zp_t).all() & (_info == 0)
+        self._nystrom_G = torch.where(good, torch.add(G0, Zp_t.T, alpha=14.142135623730951).mul_(0.05), G0)   # 0.05 G0 + Zp / sqrt(2)
+        return Zp_t @ self._Linv                            # (L^-T Zp)^T
 
     def _ao_cache_for(self, nao, npts, ncomp):
         """AO values on this rank's grid points are kept resident between SCF cycles when they fit in a quarter
@@ -192,7 +240,7 @@ class RKS(RHF):
         self._nelec_grid = tail[0]
         F = torch.empty_like(J)
         eng.fock_energy(self._h1, J, K, vxc, dm, 0.5 * hyb, F, part)
-        return F, tail[1:2]
+        return F, tail[0:2]      # [N_elec, E_xc]: the last entry is added to the energy, the first validates the quadrature
 
     def _xc_reduced(self, dm):
         nelec, exc, vxc, hyb = self.nr_rks(dm)

@@ -74,6 +74,8 @@ def lib():
         L.mi_diis_combine.argtypes = [vp, vp, dp, ctypes.c_int, vp, vp]
         L.mi_diis_dots.argtypes = [vp, vp, vp, ctypes.c_int, dp, vp]
         L.mi_diis_dots_dev.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp]
+        L.mi_xc_rho_mo.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, vp, vp, vp]
+        L.mi_xc_rho_lowrank.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, vp, vp, vp]
         L.mi_diis_solve.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mi_diis_combine_dev.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp]
         i64 = ctypes.c_int64
@@ -312,6 +314,25 @@ class Engine:
         rho = self._new(4 if deriv else 1, ng)
         _check(lib().mi_xc_rho(self._h, ao.data_ptr(), C.data_ptr(), ng, int(deriv), rho.data_ptr(), self._stream()))
         return rho
+
+    def xc_rho_mo(self, psi, deriv=1, with_tau=False):
+        """rho[(1|4)][ng] (and tau[ng]) from occupied-orbital values psi[(1|4)][nocc][ng] of a density D = Z Z^T."""
+        ng, nocc = psi.shape[-1], psi.shape[-2]
+        rho = self._new(4 if deriv else 1, ng)
+        tau = self._new(ng) if with_tau else None
+        _check(lib().mi_xc_rho_mo(self._h, psi.data_ptr(), nocc, ng, int(deriv), rho.data_ptr(),
+                                  tau.data_ptr() if tau is not None else None, self._stream()))
+        return (rho, tau) if with_tau else rho
+
+    def xc_rho_lowrank(self, ao, Zp, deriv=1, with_tau=False):
+        """rho[(1|4)][ng] (and tau[ng]) of D = Z Z^T straight from the AO values: Zp [nao, ldz] (zero-padded columns)."""
+        ng = ao.shape[-1]
+        assert Zp.is_contiguous() and Zp.shape[0] == self.nao
+        rho = self._new(4 if deriv else 1, ng)
+        tau = self._new(ng) if with_tau else None
+        _check(lib().mi_xc_rho_lowrank(self._h, ao.data_ptr(), Zp.data_ptr(), Zp.shape[1], ng, int(deriv), rho.data_ptr(),
+                                       tau.data_ptr() if tau is not None else None, self._stream()))
+        return (rho, tau) if with_tau else rho
 
     def xc_eval_spin(self, terms, rhoa, rhob, weights, gga=True):
         """Spin-polarised functionals: (exc[ng], wva[(1|4)][ng], wvb[(1|4)][ng])."""

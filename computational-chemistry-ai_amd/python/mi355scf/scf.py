@@ -333,7 +333,8 @@ class SCF:
 
     def _fock_energy(self, dm, part):
         """F = h + veff(D) on device; `part` receives the fixed-order partial sums of E_elec(D) (fused kernel).  Returns
-        (F, extra): `extra` is a one-element device tensor to add to the energy (E_xc) or None.  Overridden by RKS."""
+        (F, extra): `extra` is None or a device tensor whose LAST element is added to the energy (E_xc); RKS passes
+        [N_elec on the grid, E_xc] so that the host can also validate the quadrature of the cycle.  Overridden by RKS."""
         J, K = self._jk(dm)
         F = torch.empty_like(J)
         self.engine.fock_energy(self._h1, J, K, None, dm, 0.5, F, part)
@@ -558,12 +559,15 @@ class SCF:
 
     _PIN_DOUBLES = 16384
 
-    def _after_density_launch(self, st, dm, next_cycle, sp2_tr=None, hist_shape=None):
+    def _after_density_launch(self, st, dm, next_cycle, sp2_tr=None, hist_shape=None, projector=False):
         """Device part of `_after_density`: everything is queued, the scalars of the cycle are on their way to pinned host
         memory (asynchronous copy + event) when this returns -- the caller may queue more work before `_after_density_finish`
         waits for them."""
-        Li, L = self._Linv, self._L
+        Li = self._Linv
         dm = dm.contiguous()
+        # `projector`: dm = L^-T (2 X) L^-1 with X (= st["dmo"] / 2) an idempotent of rank n_occ -- lets the XC quadrature of
+        # RKS work from occupied-orbital values instead of the full density matrix (dft.RKS._occ_factor)
+        self._xc_projector = (dm, st["dmo"], st["nocc"]) if projector else None
         nb = self.engine.reduce_blocks
         self.n_fock_builds = getattr(self, "n_fock_builds", 0) + 1
         # partial sums of [E_elec | |[F',D']|^2]: on the planned path they go right in front of the trace history
@@ -595,7 +599,7 @@ class SCF:
         if inplace and extra is None:
             packed = ws["scal"][self._HEAD_MAX - 2 * nb:self._HEAD_MAX + sp2_tr.numel()]   # already contiguous: no gather kernel
         else:
-            parts = [part] + ([extra.reshape(1)] if extra is not None else []) + ([sp2_tr] if sp2_tr is not None else [])
+            parts = [part] + ([extra.reshape(-1)] if extra is not None else []) + ([sp2_tr] if sp2_tr is not None else [])
             packed = torch.cat(parts) if len(parts) > 1 else part
         # Sharded runs: every rank holds the same all-reduced J/K(/Vxc) and the replicated algebra above is free of atomics
         # (fixed-order partial sums), so these scalars are bit-identical on all ranks and steer identical control flow --
@@ -603,7 +607,8 @@ class SCF:
         if self._nranks > 1 and self.sync_control:
             from . import parallel
             parallel.broadcast0(packed, self._pg)
-        ctx = dict(dm=dm, fock=fock, fo=fo, nb=nb, has_extra=extra is not None, has_tr=sp2_tr is not None, hist_shape=hist_shape,
+        ctx = dict(dm=dm, fock=fock, fo=fo, nb=nb, n_extra=0 if extra is None else extra.numel(), has_tr=sp2_tr is not None,
+                   hist_shape=hist_shape, lowrank=self._xc_projector is not None,
                    packed=packed, event=None)
         k = packed.numel()
         if k <= self._PIN_DOUBLES:
@@ -628,9 +633,17 @@ class SCF:
         e_el = float(vals[:nb].sum())                  # numpy's pairwise sum: the same order on every rank
         c2 = float(vals[nb:2 * nb].sum())
         pos = 2 * nb
-        if ctx["has_extra"]:
-            e_el += float(vals[pos])
-            pos += 1
+        if ctx["n_extra"]:
+            ne = ctx["n_extra"]
+            if ne == 2 and ctx["lowrank"]:
+                # RKS: electron count of this cycle's quadrature.  The density came from a low-rank factor of the projector
+                # (dft.RKS._occ_factor): a failed factorisation (NaN, or a count off by more than the grid error) sends the
+                # cycle through the redo path, which uses the full density matrix
+                nel = float(vals[pos])
+                if not (abs(nel - 2.0 * st["nocc"]) < 0.01 * 2.0 * st["nocc"]):
+                    return False
+            e_el += float(vals[pos + ne - 1])
+            pos += ne
         if ctx["has_tr"]:
             hist = vals[pos:]
             shape = ctx["hist_shape"]
@@ -726,10 +739,10 @@ class SCF:
             else:
                 st.pop("mo_e", None)
             dm = Li.T @ dmo @ Li
-        saved = (st["dmo"], st["diis"].count) if tr_dev is not None else None
+        saved = (st["dmo"], st["diis"].count)
         st["dmo"] = dmo
         e_prev = st["e_tot"]
-        ctx = self._after_density_launch(st, dm, st["cycle"] + 1, sp2_tr=tr_dev, hist_shape=hist_shape)
+        ctx = self._after_density_launch(st, dm, st["cycle"] + 1, sp2_tr=tr_dev, hist_shape=hist_shape, projector=True)
         nxt = self._front(st) if (use_diis and not want_mo) else None
         ok = self._after_density_finish(st, ctx, e_prev, nocc)
         if not ok:

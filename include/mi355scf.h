@@ -202,6 +202,14 @@ int mi_eval_ao(mi_ctx *ctx, const double *d_coords, int64_t ng, int deriv, doubl
 /* rho and grad rho from d_C = D @ ao0 ([nao][ng]): d_rho[(1|4)][ng].  (numint.eval_rho [MEM]) */
 int mi_xc_rho(mi_ctx *ctx, const double *d_ao, const double *d_C, int64_t ng, int deriv, double *d_rho,
               void *stream);
+/* Round 2: the same from occupied-orbital values d_psi[(1|4)][nocc][ng] = Z^T ao of a factorised density D = Z Z^T
+ * (numint.eval_rho2 [MEM], what PySCF uses when mo_coeff / mo_occ are known): rho = sum psi^2, grad rho = 2 sum psi grad psi,
+ * and (d_tau non-null, deriv = 1) the kinetic-energy density tau = 1/2 sum |grad psi|^2 of the meta-GGAs. */
+int mi_xc_rho_mo(mi_ctx *ctx, const double *d_psi, int nocc, int64_t ng, int deriv, double *d_rho, double *d_tau, void *stream);
+/* Both steps fused (psi never stored): d_Zp[nao][ldz] = Z with the orbital index fastest, zero-padded to ldz = a multiple of
+ * 24 (deriv = 1) or 32 (deriv = 0) columns; d_ao as in mi_xc_rho. */
+int mi_xc_rho_lowrank(mi_ctx *ctx, const double *d_ao, const double *d_Zp, int ldz, int64_t ng, int deriv, double *d_rho,
+                      double *d_tau, void *stream);
 
 /* Closed-shell XC energy density and potential on the grid.  kinds[]: 1 Slater, 2 B88, 3 VWN-RPA,
  * 4 VWN5, 5 LYP, 6 PBE-x, 7 PBE-c with weights coefs[].  Outputs (any may be NULL): d_exc[ng] energy
