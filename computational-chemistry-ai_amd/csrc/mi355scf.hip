@@ -5339,6 +5339,8 @@ __global__ __launch_bounds__(256) void xc_vmat_kernel(const double *__restrict__
     const int64_t kbeg = (int64_t)blockIdx.z * kchunk, kend = min(ng, kbeg + kchunk);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qm = (wave >> 1) * 32, qn = (wave & 1) * 32;
+    // which of this wave's 2 x 2 blocks of 16 rows / columns lie inside the matrix (wave-uniform)
+    const bool va0 = m0 + qm < nao, va1 = m0 + qm + 16 < nao, vb0 = n0 + qn < nao, vb1 = n0 + qn + 16 < nao;
     d4_t acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -5369,15 +5371,28 @@ __global__ __launch_bounds__(256) void xc_vmat_kernel(const double *__restrict__
         }
         __syncthreads();
         if (k0 + VM_KS < kend) gload(k0 + VM_KS);
+        if (va1 && vb1) {
 #pragma unroll 4
-        for (int kk = 0; kk < VM_KS; kk += 4) {
-            const int kc = kk + (lane >> 4);
-            double a0 = Pa[qm + (lane & 15)][kc], a1 = Pa[qm + 16 + (lane & 15)][kc];
-            double b0 = Pb[qn + (lane & 15)][kc], b1 = Pb[qn + 16 + (lane & 15)][kc];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            for (int kk = 0; kk < VM_KS; kk += 4) {
+                const int kc = kk + (lane >> 4);
+                double a0 = Pa[qm + (lane & 15)][kc], a1 = Pa[qm + 16 + (lane & 15)][kc];
+                double b0 = Pb[qn + (lane & 15)][kc], b1 = Pb[qn + 16 + (lane & 15)][kc];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        } else if (va0 && vb0) {
+            // edge tile (nao is not a multiple of 64): only the 16x16 blocks that reach into the matrix are multiplied, so the
+            // mostly empty last tile row / column costs a half or a quarter of a full tile instead of the same
+#pragma unroll 4
+            for (int kk = 0; kk < VM_KS; kk += 4) {
+                const int kc = kk + (lane >> 4);
+                const double a0 = Pa[qm + (lane & 15)][kc], b0 = Pb[qn + (lane & 15)][kc];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                if (vb1) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Pb[qn + 16 + (lane & 15)][kc], acc[0][1], 0, 0, 0);
+                if (va1) acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[qm + 16 + (lane & 15)][kc], b0, acc[1][0], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
