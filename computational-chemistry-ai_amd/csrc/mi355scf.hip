@@ -5144,6 +5144,91 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *__restrict
     }
 }
 
+// Planned purification, one matrix per pass: the polynomial of the NEXT pass is applied in the epilogue of this one,
+//   pass k:  reads X_k (pass 0: b_in F + c_in I formed while loading), computes the tile of X_k^2 and the traces of X_k, X_k^2,
+//            writes X_{k+1} = a X_k^2 + b X_k + c I   (last pass: a = c = 0, b = out_scale: the result itself),
+// so a pass loads two row panels and stores one tile where the two-matrix version loaded four and stored two.  Same triangular
+// grid, same mirror stores, same MFMA/K-split order as sp2_fused_kernel: the traces are bit-identical to that kernel's.
+template <int MAXM>
+__global__ __launch_bounds__(256) void sp2_plan_kernel(const double *__restrict__ Xin, int n, int kpad, double b_in, double c_in,
+                                                       double *__restrict__ Xout, double *__restrict__ trc, Sp2Coef nx)
+{
+    extern __shared__ double lds[];
+    double *Pa = lds;                       // [16][kpad+4]  rows i0..i0+15 of X_k
+    double *Pb = lds + 16 * (kpad + 4);     // [16][kpad+4]  rows j0..j0+15 of X_k
+    double *red = Pb + 16 * (kpad + 4);     // [4][256]
+    const int ldp = kpad + 4;
+    int bI = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((bI + 1) * (bI + 2) / 2 <= (int)blockIdx.x) bI++;
+    while (bI * (bI + 1) / 2 > (int)blockIdx.x) bI--;
+    const int bJ = (int)blockIdx.x - bI * (bI + 1) / 2;
+    const int i0 = bI * 16, j0 = bJ * 16;
+    const int t = threadIdx.x, r = t >> 4, c = t & 15;
+    const bool ra = i0 + r < n, rb = j0 + r < n;
+    const double *xa_row = Xin + (size_t)(i0 + r) * n, *xb_row = Xin + (size_t)(j0 + r) * n;
+    const int mtot = kpad >> 4;
+    for (int m0 = 0; m0 < mtot; m0 += MAXM) {
+        double xa[MAXM], xb[MAXM];
+#pragma unroll
+        for (int u = 0; u < MAXM; u++) {
+            const int k = c + 16 * (m0 + u);
+            const bool in = (m0 + u < mtot) && k < n;
+            xa[u] = (in && ra) ? xa_row[k] : 0.0;
+            xb[u] = (in && (bI != bJ) && rb) ? xb_row[k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < MAXM; u++) {
+            const int k = c + 16 * (m0 + u);
+            if (m0 + u < mtot) {   // zero padding (k >= n, rows >= n) must stay zero: the identity term only on real diagonal elements
+                const double da = (ra && k < n && k == i0 + r) ? c_in : 0.0, db = (rb && k < n && k == j0 + r) ? c_in : 0.0;
+                const double va = fma(b_in, xa[u], da);
+                Pa[r * ldp + k] = va;
+                Pb[r * ldp + k] = (bI != bJ) ? fma(b_in, xb[u], db) : va;
+            }
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kq = kpad / 4; // k-range per wave (multiple of 4)
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    const double *pa = Pa + (lane & 15) * ldp + wave * kq + (lane >> 4);
+    const double *pb = Pb + (lane & 15) * ldp + wave * kq + (lane >> 4);
+    for (int k = 0; k < kq; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k], pb[k], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[wave * 256 + q * 64 + lane] = acc[q];
+    __syncthreads();
+    if (wave == 0) {
+        double tr2 = 0.0, tr1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double v = (red[q * 64 + lane] + red[256 + q * 64 + lane]) + (red[512 + q * 64 + lane] + red[768 + q * 64 + lane]);
+            int col = lane & 15, row = (lane >> 4) + 4 * q; // f64 MFMA C/D layout
+            int gi = i0 + row, gj = j0 + col;
+            if (gi < n && gj < n) {
+                const double xc = Pa[row * ldp + gj];
+                const double dg = (gi == gj) ? nx.c : 0.0;
+                Xout[(size_t)gi * n + gj] = fma(nx.a, v, fma(nx.b, xc, dg));
+                if (bI != bJ) Xout[(size_t)gj * n + gi] = fma(nx.a, v, nx.b * Pb[col * ldp + gi]);
+                if (gi == gj) { tr2 += v; tr1 += xc; }
+            }
+        }
+        if (bI == bJ) {
+            for (int o = 32; o > 0; o >>= 1) { tr1 += __shfl_xor(tr1, o); tr2 += __shfl_xor(tr2, o); }
+            if (lane == 0) { trc[2 * bI] = tr1; trc[2 * bI + 1] = tr2; }
+        }
+    }
+}
+typedef void (*sp2_plan_fn)(const double *, int, int, double, double, double *, double *, Sp2Coef);
+static sp2_plan_fn sp2_plan_for(int kpad)
+{
+    const int m = kpad >> 4;
+    if (m <= 8) return sp2_plan_kernel<8>;
+    if (m <= 12) return sp2_plan_kernel<12>;
+    if (m <= 16) return sp2_plan_kernel<16>;
+    if (m <= 20) return sp2_plan_kernel<20>;
+    return sp2_plan_kernel<16>; // two batches
+}
+
 typedef void (*sp2_fused_fn)(const double *, const double *, const double *, int, int, int, double, double *, double *, double *, Sp2Coef);
 template <bool PLAN> static sp2_fused_fn sp2_fused_for_t(int kpad)
 {
@@ -5227,8 +5312,8 @@ extern "C" int mi_sp2_iterate_pingpong(mi_ctx *c, double *d_A, double *d_B, int 
 // last diagonalisation) and fixes the whole sequence of quadratics in advance -- each step folds one band of the spectrum
 // about a point inside it, (x - c)^2 or -(x - c)^2, and rescales to [0, 1]: about half the steps of trace-correcting SP2.
 // Pass 0 maps the Fock matrix, X_0 = coef[1] F + coef[2] I; pass k = 1..nit applies X_k = a X_{k-1}^2 + b X_{k-1} + c I
-// (coef[3k..3k+2]); every pass also leaves X_k^2 and the partial traces (validation by the caller: tr(X - X^2), tr X).
-// d_F is only read; d_A, d_B: two [X | X2] buffers of 2 n^2 doubles; *d_res = the one holding {X_nit, X_nit^2}.
+// (coef[3k..3k+2]); every pass leaves the partial traces of X_k and X_k^2 (validation by the caller: tr(X - X^2), tr X).
+// d_F is only read; d_A, d_B: two buffers of (at least) n^2 doubles; *d_res = the one holding out_scale * X_nit.
 extern "C" int mi_sp2_iterate_planned(mi_ctx *c, const double *d_F, double *d_A, double *d_B, int nit, const double *coef, double out_scale,
                                       double *d_tr, double **d_tr_out, double **d_res, void *stream)
 {
@@ -5242,13 +5327,15 @@ extern "C" int mi_sp2_iterate_planned(mi_ctx *c, const double *d_F, double *d_A,
     dim3 grid(nb * (nb + 1) / 2), block(256);
     const size_t nn = (size_t)n * n;
     constexpr int TS = 2 * SP2_TRS;
-    const sp2_fused_fn kern = sp2_fused_for_t<true>(kpad);
+    const sp2_plan_fn kern = sp2_plan_for(kpad);
+    const double osc = out_scale != 0.0 ? out_scale : 1.0;
+    auto next_coef = [&](int k) {   // polynomial applied in the epilogue of pass k: X_{k+1}, or the (scaled) result after the last pass
+        return k < nit ? Sp2Coef{coef[3 * (k + 1)], coef[3 * (k + 1) + 1], coef[3 * (k + 1) + 2], 0.0} : Sp2Coef{0.0, osc, 0.0, 0.0};
+    };
     double *cur = d_A, *nxt = d_B;
-    hipLaunchKernelGGL(kern, grid, block, shm, st, d_F, d_F, d_tr, 1, n, kpad, 0.0, cur, cur + nn, d_tr,
-                       Sp2Coef{0.0, coef[1], coef[2], nit == 0 ? out_scale : 0.0});
+    hipLaunchKernelGGL(kern, grid, block, shm, st, d_F, n, kpad, coef[1], coef[2], cur, d_tr, next_coef(0));
     for (int it = 1; it <= nit; it++) {
-        hipLaunchKernelGGL(kern, grid, block, shm, st, cur, cur + nn, d_tr, 0, n, kpad, 0.0, nxt, nxt + nn, d_tr + TS * it,
-                           Sp2Coef{coef[3 * it], coef[3 * it + 1], coef[3 * it + 2], it == nit ? out_scale : 0.0});
+        hipLaunchKernelGGL(kern, grid, block, shm, st, cur, n, kpad, 1.0, 0.0, nxt, d_tr + TS * it, next_coef(it));
         std::swap(cur, nxt);
     }
     HIPCHK(hipGetLastError());

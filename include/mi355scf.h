@@ -170,9 +170,10 @@ int mi_sp2_iterate_pingpong(mi_ctx *ctx, double *d_A, double *d_B, int nit, doub
 /* Planned purification: the whole sequence of quadratics is fixed by the caller from bounds of the spectrum (outer) and of
  * the HOMO / LUMO (inner) -- see mi355scf/sp2plan.py.  coef[3*(nit+1)]: pass 0 forms X_0 = coef[1] F + coef[2] I from the
  * (orthonormal-basis) Fock matrix d_F, pass k applies X_k = coef[3k] X^2 + coef[3k+1] X + coef[3k+2] I.  Buffers and trace
- * output as in mi_sp2_iterate_pingpong (the caller validates tr(X - X^2) and tr X of the last pass).  The stored result of
- * the LAST pass is out_scale * X (2 = closed-shell density matrix in the orthonormal basis; 0 or 1 = the projector itself);
- * the traces are always those of the unscaled X. */
+ * of every pass as in mi_sp2_iterate_pingpong (the caller validates tr(X - X^2) and tr X of the last pass).  One matrix per
+ * pass: d_A, d_B need n^2 doubles each, *d_res = the one that holds the result out_scale * X_nit (2 = closed-shell density
+ * matrix in the orthonormal basis; 0 or 1 = the projector itself; X_nit^2 is not stored); the traces are those of the
+ * unscaled X. */
 int mi_sp2_iterate_planned(mi_ctx *ctx, const double *d_F, double *d_A, double *d_B, int nit, const double *coef, double out_scale,
                            double *d_tr, double **d_tr_out, double **d_res, void *stream);
 

@@ -17,7 +17,7 @@ d = [(rows[b][0] - rows[a][0]) / 1e3 for a, b in zip(run, run[1:])]
 print("cycles in the longest run:", len(run) - 1, "J/K-to-J/K us: min %.0f median %.0f max %.0f" % (min(d), statistics.median(d), max(d)))
 print("last 12:", [round(x) for x in d[-12:]])
 fam = collections.defaultdict(float); idle = 0.0; tot = 0.0; n = 0
-pairs = [(a, b) for a, b in zip(run, run[1:]) if sum("sp2_fused" in r[2] for r in rows[a:b]) >= 4]   # SCF cycles only (not the back-to-back roofline launches)
+pairs = [(a, b) for a, b in zip(run, run[1:]) if sum("sp2_" in r[2] for r in rows[a:b]) >= 4]   # SCF cycles only (not the back-to-back roofline launches)
 for a, b in pairs[-50:]:
     seg = rows[a:b]
     tot += rows[b][0] - rows[a][0]; n += 1
