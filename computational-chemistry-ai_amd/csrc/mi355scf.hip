@@ -4994,7 +4994,8 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                     } else if (mfma_worthwhile(X.ns1 * X.ns2, X.nf, X.nscd) || mfma_worthwhile(X.ns1 * X.ns2, X.ne_p, X.nf) ||
                                (has_m && mfma_worthwhile(X.ns1 * X.ns2, X.ne_m, X.nf))) {
                         // (two or four waves sharing one quartet's LDS blocks -- eri_grad_contract<128|256, true> -- were measured at
-                        // -2 % / +8 %: the kernel is parked on its dependent load chain, 70 % of wave cycles, not short of lanes)
+                        // -2 % / +8 %, the six density sub-blocks of G staged in LDS first at +2 %: the kernel is parked 70 % of its
+                        // wave cycles, but neither on a shortage of lanes nor on the G gather)
                         if (shm > 64 * 1024)
                             HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
                         hipLaunchKernelGGL((eri_grad_contract<64, true>), dim3(nb), dim3(64), shm, st, X);
