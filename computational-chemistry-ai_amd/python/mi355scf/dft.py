@@ -98,6 +98,11 @@ class RKS(RHF):
         lo, hi = self._grid_range(ng)
         # grid block: as large as a ~1.5 GB working set allows (fewer launches for small molecules), at least grid_block
         B = max(self.grid_block, int(1.5e9 / (48.0 * n)) // 1024 * 1024)
+        if hi - lo <= 1.5 * B:
+            B = max(hi - lo, 1)   # no small remainder block: its kernels would be pure launch latency (0.15 ms per build on benzene/cc-pVTZ)
+        else:                     # equal blocks instead of full ones plus a short tail
+            nblk = (hi - lo + B - 1) // B
+            B = ((hi - lo + nblk - 1) // nblk + 1023) // 1024 * 1024
         cache = self._ao_cache_for(n, hi - lo, 4 if gga else 1)
         Zt = self._occ_factor(dm)
         if Zt is not None:   # [nao, ldz] with the orbital index fastest, zero-padded to the kernel's chunk (24 GGA / 32 LDA)

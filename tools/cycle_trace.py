@@ -11,13 +11,16 @@ for a, b in zip(jk, jk[1:]):
     else: runs.append(cur); cur = [b]
 runs.append(cur)
 run = max(runs, key=len)
+if len(sys.argv) > 2 and sys.argv[2] == "rks":   # the B3LYP leg: cycles that contain the XC kernels
+    run = jk
 print("runs of J/K launches (length):", [len(r) for r in runs])
 import statistics
 d = [(rows[b][0] - rows[a][0]) / 1e3 for a, b in zip(run, run[1:])]
 print("cycles in the longest run:", len(run) - 1, "J/K-to-J/K us: min %.0f median %.0f max %.0f" % (min(d), statistics.median(d), max(d)))
 print("last 12:", [round(x) for x in d[-12:]])
 fam = collections.defaultdict(float); idle = 0.0; tot = 0.0; n = 0
-pairs = [(a, b) for a, b in zip(run, run[1:]) if sum("sp2_" in r[2] for r in rows[a:b]) >= 4]   # SCF cycles only (not the back-to-back roofline launches)
+want = "xc_vmat" if (len(sys.argv) > 2 and sys.argv[2] == "rks") else "sp2_"
+pairs = [(a, b) for a, b in zip(run, run[1:]) if sum("sp2_" in r[2] for r in rows[a:b]) >= 4 and any(want in r[2] for r in rows[a:b]) and rows[b][0] - rows[a][0] < 6_000_000]   # SCF cycles only (not the back-to-back roofline launches)
 for a, b in pairs[-50:]:
     seg = rows[a:b]
     tot += rows[b][0] - rows[a][0]; n += 1
