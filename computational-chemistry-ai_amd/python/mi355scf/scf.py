@@ -396,7 +396,8 @@ class SCF:
             if abs(err) < self.sp2_tol and abs(float(tr[0]) - target) < 1e-8:
                 self._sp2_iters = nit
                 self._sp2_validated = True
-                return 2.0 * X if self._sp2_orth else 2.0 * (Li.T @ X @ Li)
+                Xs = X + X.T                       # exactly symmetric 2 X (see _sp2_planned_gemm)
+                return Xs if self._sp2_orth else Li.T @ Xs @ Li
             nit += 8
         return None
 
@@ -457,7 +458,7 @@ class SCF:
             X = buf[cur][2:].view(n, n)
             cur = 1 - cur
         torch.matmul(X, X, out=X2)
-        return 2.0 * X, torch.stack([torch.trace(X), torch.trace(X2)])
+        return X + X.T, torch.stack([torch.trace(X), torch.trace(X2)])   # exactly symmetric 2 X (see _sp2_planned_gemm)
 
     _HEAD_MAX = 4096   # doubles reserved in front of the planned-path trace history for [E partials | |g|^2 partials | extra]
 
@@ -467,6 +468,8 @@ class SCF:
         fills afterwards, so the cycle's scalars leave the device as ONE contiguous copy without a gather kernel."""
         eng = self.engine
         n = fo.shape[0]
+        if not (n <= self.sp2_fused_max and self.sp2_fused):
+            return self._sp2_planned_gemm(fo, nocc)
         ws = getattr(self, "_sp2p", None)
         if ws is None or ws["n"] != n:
             mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
@@ -477,12 +480,48 @@ class SCF:
         self._sp2_hist_shape = (coef.shape[0], (n + 15) // 16)
         return res[0], tr[:off + 64]   # a view of the ping-pong buffers: consumed by this cycle's Fock build, before the next pass
 
+    sp2_planned_gemm = True   # N > sp2_fused_max: the same planned sequence with one rocBLAS DGEMM (addmm) per pass
+
+    def _sp2_plannable(self, n):
+        return (n <= self.sp2_fused_max and self.sp2_fused) or self.sp2_planned_gemm
+
+    def _sp2_planned_gemm(self, fo, nocc):
+        """Planned purification for matrices beyond the fused kernel (ibuprofen N = 573, C60 N = 840): X_{k+1} = a X_k^2 + b X_k
+        + c I as ONE `addmm` (rocBLAS DGEMM with beta) plus a diagonal shift per pass -- half the passes of the trace-
+        correcting recursion of `_sp2_fused_async`, and no branch decisions on the device.  Only the last pass is checked:
+        tr X and tr X^2 = |X|_F^2 (X is symmetric) travel to the host with the cycle's other scalars."""
+        n = fo.shape[0]
+        coef = self._sp2_plan[:self._sp2_plan_len + 1]
+        buf = getattr(self, "_sp2g", None)
+        if buf is None or buf[0].shape[0] != n:
+            buf = self._sp2g = [torch.empty(n, n, dtype=torch.float64, device=fo.device) for _ in range(3)]
+        X = torch.mul(fo, float(coef[0, 1]), out=buf[0])
+        X.diagonal().add_(float(coef[0, 2]))
+        cur, nit = 0, coef.shape[0] - 1
+        for k in range(1, nit + 1):
+            a, b, c = (float(v) for v in coef[k])
+            Y = torch.addmm(X, X, X, beta=b, alpha=a, out=buf[(cur + 1) % 3])
+            cur = (cur + 1) % 3
+            if c != 0.0:
+                Y.diagonal().add_(c)
+            if k % 4 == 0 or k == nit:
+                # a library GEMM does not return X.X exactly symmetric, and the antisymmetric part A obeys A <- a (SA + AS) + b A:
+                # it can double per pass while the gap is being opened (1e-16 -> 1e-12 over 20 passes, measured).  The J/K kernel
+                # reads one triangle of D, so an asymmetric D shows up as 1e-9 Ha cycle-to-cycle jitter of a 650 Ha energy
+                # (tools/noise_check.py; the fused kernel's mirror stores keep X exactly symmetric)
+                Y = torch.add(Y, Y.T, out=buf[(cur + 1) % 3]).mul_(0.5)
+                cur = (cur + 1) % 3
+            X = Y
+        self._sp2_hist_shape = None
+        tr = torch.stack([torch.trace(X), torch.sum(X * X)])
+        return 2.0 * X, tr
+
     def _sp2_replan(self, mo_e, nocc):
         """New plan from the eigenvalues of the (orthonormal-basis) Fock matrix just diagonalised."""
         from . import sp2plan
         e = mo_e.cpu().numpy() if torch.is_tensor(mo_e) else np.asarray(mo_e)
         self._sp2_plan = None
-        if self.sp2_planned and self.eig_method == "sp2" and 0 < nocc < len(e) and len(e) <= self.sp2_fused_max and self.sp2_fused:
+        if self.sp2_planned and self.eig_method == "sp2" and 0 < nocc < len(e) and self._sp2_plannable(len(e)):
             b = sp2plan.bounds_from_spectrum(e, nocc, self.sp2_inner_margin, self.sp2_outer_margin)
             self._sp2_plan = sp2plan.plan(*b)
             if self._sp2_plan is not None:
@@ -680,7 +719,7 @@ class SCF:
         cycle cannot take the planned path."""
         nocc = st["nocc"]
         n = self._Linv.shape[0]
-        if not (self.pipeline and self.eig_method == "sp2" and self.sp2_planned and self.sp2_fused and n <= self.sp2_fused_max
+        if not (self.pipeline and self.eig_method == "sp2" and self.sp2_planned and self._sp2_plannable(n)
                 and 0 < nocc < n and not self.level_shift and self._sp2_plan is not None
                 and st["cycle"] + 1 >= self.diis_start_cycle and st["diis"].count > 0):
             return None
@@ -716,8 +755,7 @@ class SCF:
                 fo = fo + self.level_shift * (torch.eye(fo.shape[0], dtype=fo.dtype, device=fo.device) - 0.5 * st["dmo"])
             use_sp2 = self.eig_method == "sp2" and not want_mo
             n = fo.shape[0]
-            planned_ok = (use_sp2 and self.sp2_planned and self.sp2_fused and n <= self.sp2_fused_max and 0 < nocc < n
-                          and not self.level_shift)
+            planned_ok = (use_sp2 and self.sp2_planned and self._sp2_plannable(n) and 0 < nocc < n and not self.level_shift)
             dmo = None
             if planned_ok and self._sp2_plan is not None and not st.get("_redo"):
                 dmo, tr_dev = self._sp2_planned_async(fo, nocc)
