@@ -2831,13 +2831,18 @@ __global__ __launch_bounds__(256) void diis_dots_kernel(const double *hist, cons
     if (threadIdx.x == 0) out[blockIdx.x * DIIS_NS + blockIdx.y] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-extern "C" int mi_diis_dots_dev(mi_ctx *c, const double *d_hist_e, const double *d_e, int n, double *d_out, void *stream)
+extern "C" int mi_diis_dots_dev_n(mi_ctx *c, const double *d_hist_e, const double *d_e, int n, int64_t len, double *d_out, void *stream)
 {
-    if (!c || n < 1 || n > 64 || !d_out) return fail("mi_diis_dots_dev: bad argument");
-    size_t nn = (size_t)c->nao * c->nao;
-    hipLaunchKernelGGL(diis_dots_kernel, dim3(n, DIIS_NS), dim3(256), 0, (hipStream_t)stream, d_hist_e, d_e, nn, d_out);
+    if (!c || n < 1 || n > 64 || len < 1 || !d_out) return fail("mi_diis_dots_dev_n: bad argument");
+    hipLaunchKernelGGL(diis_dots_kernel, dim3(n, DIIS_NS), dim3(256), 0, (hipStream_t)stream, d_hist_e, d_e, (size_t)len, d_out);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+extern "C" int mi_diis_dots_dev(mi_ctx *c, const double *d_hist_e, const double *d_e, int n, double *d_out, void *stream)
+{
+    if (!c) return fail("mi_diis_dots_dev: bad argument");
+    return mi_diis_dots_dev_n(c, d_hist_e, d_e, n, (int64_t)c->nao * c->nao, d_out, stream);
 }
 
 // CDIIS without the host: one small workgroup adds the Gram-row partials of the newest error vector in index order, updates the
@@ -2956,13 +2961,18 @@ __global__ void diis_combine_dev_kernel(const double *hist, const double *coef, 
     out[idx] = s;
 }
 
-extern "C" int mi_diis_combine_dev(mi_ctx *c, const double *d_hist, const double *d_coef, int n, double *d_out, void *stream)
+extern "C" int mi_diis_combine_dev_n(mi_ctx *c, const double *d_hist, const double *d_coef, int n, int64_t len, double *d_out, void *stream)
 {
-    if (!c || !d_hist || !d_coef || !d_out || n < 1 || n > DIIS_MAXM) return fail("mi_diis_combine_dev: bad argument");
-    size_t nn = (size_t)c->nao * c->nao;
-    hipLaunchKernelGGL(diis_combine_dev_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_hist, d_coef, n, nn, d_out);
+    if (!c || !d_hist || !d_coef || !d_out || n < 1 || n > DIIS_MAXM || len < 1) return fail("mi_diis_combine_dev_n: bad argument");
+    hipLaunchKernelGGL(diis_combine_dev_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_hist, d_coef, n, (size_t)len, d_out);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+extern "C" int mi_diis_combine_dev(mi_ctx *c, const double *d_hist, const double *d_coef, int n, double *d_out, void *stream)
+{
+    if (!c) return fail("mi_diis_combine_dev: bad argument");
+    return mi_diis_combine_dev_n(c, d_hist, d_coef, n, (int64_t)c->nao * c->nao, d_out, stream);
 }
 
 extern "C" int mi_diis_dots(mi_ctx *c, const double *d_hist_e, const double *d_e, int n, double *out, void *stream)

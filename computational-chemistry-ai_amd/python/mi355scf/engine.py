@@ -76,6 +76,8 @@ def lib():
         L.mi_diis_dots_dev.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp]
         L.mi_xc_rho_mo.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, vp, vp, vp]
         L.mi_xc_rho_lowrank.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, vp, vp, vp]
+        L.mi_diis_dots_dev_n.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int64, vp, vp]
+        L.mi_diis_combine_dev_n.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int64, vp, vp]
         L.mi_diis_solve.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mi_diis_combine_dev.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp]
         i64 = ctypes.c_int64
@@ -467,14 +469,15 @@ class Engine:
         _check(lib().mi_diis_combine(self._h, hist.data_ptr(), _dp(c), len(c), out.data_ptr(), self._stream()))
 
     def diis_dots_dev(self, hist_e, e, n, out):
-        _check(lib().mi_diis_dots_dev(self._h, hist_e.data_ptr(), e.data_ptr(), n, out.data_ptr(), self._stream()))
+        # vector length from the tensors: nao^2 for RHF/RKS, 2 nao^2 for the spin-stacked pair of UHF/UKS
+        _check(lib().mi_diis_dots_dev_n(self._h, hist_e.data_ptr(), e.data_ptr(), n, e.numel(), out.data_ptr(), self._stream()))
 
     def diis_solve(self, part, m, slot, space, B, coef):
         """Pulay system of the m stored vectors solved on the device (B, coef: device tensors [space,space], [space])."""
         _check(lib().mi_diis_solve(self._h, part.data_ptr(), m, slot, space, B.data_ptr(), coef.data_ptr(), self._stream()))
 
     def diis_combine_dev(self, hist, coef, n, out):
-        _check(lib().mi_diis_combine_dev(self._h, hist.data_ptr(), coef.data_ptr(), n, out.data_ptr(), self._stream()))
+        _check(lib().mi_diis_combine_dev_n(self._h, hist.data_ptr(), coef.data_ptr(), n, out.numel(), out.data_ptr(), self._stream()))
 
     def diis_dots(self, hist_e, e, n):
         out = np.zeros(n)

@@ -39,11 +39,12 @@ def _atom_config(z):
 class DeviceDIIS:
     """Pulay CDIIS with the history on the GPU (row a10): e = (SDF)^T - SDF, subspace 8 [MEM defaults]."""
 
-    def __init__(self, eng, space=8):
+    def __init__(self, eng, space=8, nmat=1):
         n = eng.nao
         self.eng, self.space, self.count = eng, space, 0
-        self.F = torch.empty(space, n, n, dtype=torch.float64, device=eng.device)
-        self.E = torch.empty(space, n, n, dtype=torch.float64, device=eng.device)
+        shape = (space, n, n) if nmat == 1 else (space, nmat, n, n)    # nmat = 2: the spin-stacked pair of UHF / UKS
+        self.F = torch.empty(*shape, dtype=torch.float64, device=eng.device)
+        self.E = torch.empty(*shape, dtype=torch.float64, device=eng.device)
         self.B = np.zeros((space, space))
         self._e = torch.empty(n, n, dtype=torch.float64, device=eng.device)
 
@@ -462,21 +463,21 @@ class SCF:
 
     _HEAD_MAX = 4096   # doubles reserved in front of the planned-path trace history for [E partials | |g|^2 partials | extra]
 
-    def _sp2_planned_async(self, fo, nocc):
+    def _sp2_planned_async(self, fo, nocc, scale=2.0):
         """Planned purification, no host sync: (D' = 2 X, partial traces of every pass) -- validated by the caller like the
         optimistic SP2 path.  The traces land behind `_HEAD_MAX` doubles of one persistent buffer whose head the Fock build
         fills afterwards, so the cycle's scalars leave the device as ONE contiguous copy without a gather kernel."""
         eng = self.engine
         n = fo.shape[0]
         if not (n <= self.sp2_fused_max and self.sp2_fused):
-            return self._sp2_planned_gemm(fo, nocc)
+            return self._sp2_planned_gemm(fo, nocc, scale)
         ws = getattr(self, "_sp2p", None)
         if ws is None or ws["n"] != n:
             mk = lambda *s: torch.empty(*s, dtype=torch.float64, device=fo.device)
             ws = self._sp2p = dict(n=n, scal=mk(self._HEAD_MAX + 64 * 80), pp=(mk(2, n, n), mk(2, n, n)))
         coef = self._sp2_plan[:self._sp2_plan_len + 1]
         tr = ws["scal"][self._HEAD_MAX:]
-        res, off = eng.sp2_iterate_planned(fo.contiguous(), ws["pp"][0], ws["pp"][1], coef, tr, out_scale=2.0)
+        res, off = eng.sp2_iterate_planned(fo.contiguous(), ws["pp"][0], ws["pp"][1], coef, tr, out_scale=scale)
         self._sp2_hist_shape = (coef.shape[0], (n + 15) // 16)
         return res[0], tr[:off + 64]   # a view of the ping-pong buffers: consumed by this cycle's Fock build, before the next pass
 
@@ -485,7 +486,7 @@ class SCF:
     def _sp2_plannable(self, n):
         return (n <= self.sp2_fused_max and self.sp2_fused) or self.sp2_planned_gemm
 
-    def _sp2_planned_gemm(self, fo, nocc):
+    def _sp2_planned_gemm(self, fo, nocc, scale=2.0):
         """Planned purification for matrices beyond the fused kernel (ibuprofen N = 573, C60 N = 840): X_{k+1} = a X_k^2 + b X_k
         + c I as ONE `addmm` (rocBLAS DGEMM with beta) plus a diagonal shift per pass -- half the passes of the trace-
         correcting recursion of `_sp2_fused_async`, and no branch decisions on the device.  Only the last pass is checked:
@@ -514,7 +515,7 @@ class SCF:
             X = Y
         self._sp2_hist_shape = None
         tr = torch.stack([torch.trace(X), torch.sum(X * X)])
-        return 2.0 * X, tr
+        return scale * X, tr
 
     def _sp2_replan(self, mo_e, nocc):
         """New plan from the eigenvalues of the (orthonormal-basis) Fock matrix just diagonalised."""
@@ -761,7 +762,11 @@ class SCF:
                 dmo, tr_dev = self._sp2_planned_async(fo, nocc)
                 self._sp2_planned_pass = True
             elif planned_ok:
-                pass                                     # no plan yet: diagonalise below, which also yields the bounds for one
+                # no plan yet: diagonalise below, which also yields the bounds for one.  (Bounds from ~130 Lanczos steps on the
+                # projected Fock matrix instead -- HOMO, LUMO with residual bounds, Gershgorin outside -- were tried: as torch
+                # vector ops they cost as much as rocSOLVER's syevd at N = 264, 7 ms, and needed redo cycles when a Ritz value
+                # had not converged; the plan survives on the object across kernel() calls, so warm starts pay nothing.)
+                pass
             elif use_sp2 and self._sp2_validated and 0 < nocc < n and not st.get("_redo"):
                 dmo, tr_dev = self._sp2_fused_async(fo, nocc)
             elif use_sp2:

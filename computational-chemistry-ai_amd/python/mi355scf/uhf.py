@@ -128,7 +128,283 @@ class UHF(SCF):
         return ss, float(np.sqrt(4.0 * ss + 1.0))
 
     # --- SCF loop -------------------------------------------------------------------------------
+    fast_loop = True   # orthonormal-basis loop with device-side pair DIIS, planned purification per spin, pipelined step
+
     def kernel(self, dm0=None, **kw):
+        """Two loops.  The fast one (orthonormal basis, device-side pair DIIS, planned purification per spin, pipelined step)
+        needs purification plans, i.e. spectral bounds of both spins; a cold object would have to diagonalise two or three
+        times for them (7 ms each at N = 264, 40 ms at 573), which costs a short SCF more than the loop saves.  So: the first
+        SCF of an object with N >= sp2_min_nao runs the plain loop, whose final orbitals (needed for mo_energy anyway) seed the
+        plans; every later kernel() of the same object -- geometry steps, scans -- takes the fast loop.  Small molecules
+        diagonalise per cycle in either loop and always take the fast one."""
+        self._setup_once()
+        n = self.engine.nao
+        na, nb = self.mol.nelec
+        self.nelec = (na, nb)
+        warm = n < self.sp2_min_nao or self.eig_method != "sp2" or all(
+            no == 0 or sp.vals["_sp2_plan"] is not None for sp, no in zip(self._spin_states(n), (na, nb)))
+        if self.fast_loop and warm and not (self._nranks > 1 and self.sync_control):
+            return self._kernel_fast(dm0)
+        return self._kernel_plain(dm0)
+
+    def _seed_plans(self, mo_e):
+        """Purification plans of both spins from the orbital energies of a finished SCF (for the next kernel() of this object)."""
+        n = self.engine.nao
+        if self.eig_method != "sp2" or n < self.sp2_min_nao or not self.sp2_planned or self.level_shift:
+            return
+        for s_, sp in enumerate(self._spin_states(n)):
+            if 0 < self.nelec[s_] < n:
+                self._with_spin(sp, self._sp2_replan, mo_e[s_], self.nelec[s_])
+
+    scf = kernel
+
+    class _Spin:
+        """Purification state of one spin channel (plan, trimmed length, work buffers): swapped into the SCF object around the
+        calls of the shared `_sp2_*` helpers."""
+        KEYS = ("_sp2_plan", "_sp2_plan_len", "_sp2p", "_sp2g", "_sp2_hist_shape")
+
+        def __init__(self):
+            self.vals = {k: None for k in self.KEYS}
+            self.vals["_sp2_plan_len"] = 0
+
+    def _spin_states(self, n):
+        """The purification plans live on the object: a geometry optimisation (same `mf`, `kernel(dm0=...)` per step) reuses the
+        plans of the previous geometry and diagonalises nothing after its first SCF."""
+        key = (n, tuple(self.nelec))
+        if getattr(self, "_spin_key", None) != key:
+            self._spin_key, self._spin_pair = key, [UHF._Spin(), UHF._Spin()]
+        return self._spin_pair
+
+    def _with_spin(self, sp, fn, *a, **kw):
+        saved = {k: getattr(self, k, None) for k in sp.KEYS}
+        for k in sp.KEYS:
+            setattr(self, k, sp.vals[k])
+        try:
+            return fn(*a, **kw)
+        finally:
+            for k in sp.KEYS:
+                sp.vals[k] = getattr(self, k, None)
+                setattr(self, k, saved[k])
+
+    def _projector(self, st, s_, fo, nocc_s, allow_plan=True):
+        """(X_s, traces or None, hist_shape, planned?) for one spin: planned purification when a plan exists, else `eigh`
+        (which also yields the bounds for a plan).  X_s is the occupied projector (occupation 1) in the orthonormal basis."""
+        n = fo.shape[0]
+        sp = st["spin"][s_]
+        if nocc_s == 0:
+            return torch.zeros_like(fo), None, None, False
+        can_plan = (self.eig_method == "sp2" and self.sp2_planned and n >= self.sp2_min_nao and self._sp2_plannable(n)
+                    and 0 < nocc_s < n and not self.level_shift)
+        if can_plan and allow_plan and sp.vals["_sp2_plan"] is not None:
+            x, tr = self._with_spin(sp, self._sp2_planned_async, fo, nocc_s, 1.0)
+            shape, sp.vals["_sp2_hist_shape"] = sp.vals["_sp2_hist_shape"], None
+            return x, tr, shape, True
+        self.n_eigh = getattr(self, "n_eigh", 0) + 1
+        e, c = torch.linalg.eigh(fo)
+        co = c[:, :nocc_s]
+        if can_plan:
+            self._with_spin(sp, self._sp2_replan, e, nocc_s)
+        return co @ co.T, None, None, False
+
+    def _ulaunch(self, st, dm, dmo, next_cycle, trs):
+        """Device part of a cycle after the densities: Fock pair, F'_s = L^-1 F_s L^-T into the DIIS slot, error vectors
+        [F'_s, X_s] (orthonormal-basis CDIIS error of PySCF >= 2.1, spin-stacked) and their norms, Pulay solve, asynchronous
+        read-back of the scalars."""
+        eng, Li = self.engine, self._Linv
+        dm = dm.contiguous()
+        F, e_el = self._fock_pair(dm)
+        diis = st["diis"]
+        keep = next_cycle >= self.diis_start_cycle
+        slot = diis.next_slot()
+        nb = eng.reduce_blocks
+        part = torch.empty(2 * nb, dtype=torch.float64, device=dm.device)
+        fo = diis.F[slot] if keep else torch.empty_like(diis.F[0])
+        eo = diis.E[slot] if keep else torch.empty_like(diis.E[0])
+        for s_ in range(2):
+            torch.matmul(Li @ F[s_], Li.T, out=fo[s_])
+            eng.commutator_norm(fo[s_] @ dmo[s_], eo[s_], part[s_ * nb:(s_ + 1) * nb])
+        if keep:
+            diis.push_inplace()
+        parts = [e_el.reshape(1), part] + [t for t in trs if t is not None]
+        packed = torch.cat(parts)
+        ctx = dict(dm=dm, dmo=dmo, F=F, fo=fo, nb=nb, packed=packed, tr_sizes=[0 if t is None else t.numel() for t in trs], event=None)
+        k = packed.numel()
+        if k <= self._PIN_DOUBLES:
+            pin = getattr(self, "_pin", None)
+            if pin is None:
+                pin = self._pin = torch.empty(self._PIN_DOUBLES, dtype=torch.float64).pin_memory()
+                self._pin_event = torch.cuda.Event()
+            pin[:k].copy_(packed, non_blocking=True)
+            self._pin_event.record()
+            ctx["event"] = self._pin_event
+        return ctx
+
+    def _ufinish(self, st, ctx, shapes, planned, e_last):
+        """Host part: wait for the scalars, validate the purifications, update the state.  False: a purification was not
+        converged (nothing in `st` touched)."""
+        if ctx["event"] is not None:
+            ctx["event"].synchronize()
+            vals = self._pin[:ctx["packed"].numel()].numpy().copy()
+        else:
+            vals = ctx["packed"].cpu().numpy()
+        nb = ctx["nb"]
+        e_el = float(vals[0])
+        c2 = float(vals[1:1 + 2 * nb].sum())
+        pos = 1 + 2 * nb
+        for s_ in range(2):
+            k = ctx["tr_sizes"][s_]
+            if not k:
+                continue
+            hist = vals[pos:pos + k]
+            pos += k
+            nocc_s = st["nocc"][s_]
+            shape = shapes[s_]
+            if shape is not None and hist.size == shape[0] * 64:
+                h = hist.reshape(shape[0], 32, 2)[:, :shape[1], :]
+                tx, tx2 = h[:, :, 0].sum(axis=1), h[:, :, 1].sum(axis=1)
+                ok = (np.abs(tx - tx2) < self.sp2_tol) & (np.abs(tx - nocc_s) < 1e-8)
+                if not ok[-1]:
+                    return False
+                sp = st["spin"][s_]
+                sp.vals["_sp2_plan_len"] = min(sp.vals["_sp2_plan"].shape[0] - 1, max(int(np.argmax(ok)) + 1, 4))
+            else:
+                trx, trx2 = self._sp2_traces(hist)
+                if not (abs(trx - trx2) < self.sp2_tol and abs(trx - nocc_s) < 1e-8):
+                    return False
+        e_tot = e_el + st["enuc"]
+        gnorm = float(np.sqrt(max(c2, 0.0) / 2.0)) / np.sqrt(st["nvo"])
+        st.update(dm=ctx["dm"], dmo=ctx["dmo"], F=ctx["F"], fo=ctx["fo"], e_tot=e_tot, gnorm=gnorm,
+                  de=(e_tot - e_last) if e_last is not None else 0.0)
+        return True
+
+    def _ufront(self, st):
+        """Device-only head of the next cycle (pair-extrapolated F', planned purification of both spins, AO densities), queued
+        before the host waits for the current cycle's scalars.  None when either spin has no plan."""
+        if not (self.pipeline and st["cycle"] + 1 >= self.diis_start_cycle and st["diis"].count > 0 and not self.level_shift):
+            return None
+        for s_ in range(2):
+            if st["nocc"][s_] > 0 and st["spin"][s_].vals["_sp2_plan"] is None:
+                return None
+        n = self._Linv.shape[0]
+        if not (self.eig_method == "sp2" and self.sp2_planned and n >= self.sp2_min_nao and self._sp2_plannable(n)):
+            return None
+        fo = st["diis"].extrapolate()
+        return self._udensities(st, fo)
+
+    def _udensities(self, st, fo, allow_plan=True):
+        Li = self._Linv
+        xs, trs, shapes, planned = [], [], [], []
+        for s_ in range(2):
+            x, tr, shape, pl = self._projector(st, s_, fo[s_], st["nocc"][s_], allow_plan)
+            xs.append(x); trs.append(tr); shapes.append(shape); planned.append(pl)
+        dmo = torch.stack(xs)
+        dm = torch.stack([Li.T @ xs[0] @ Li, Li.T @ xs[1] @ Li])
+        return dict(fo=fo, dmo=dmo, dm=dm, trs=trs, shapes=shapes, planned=planned)
+
+    def _ustep(self, st):
+        front = st.pop("front", None)
+        if front is None:
+            if st["cycle"] >= self.diis_start_cycle and st["diis"].count > 0:
+                fo = st["diis"].extrapolate()
+            else:
+                fo = st["fo"]
+            if self.level_shift:   # F'_s + shift (1 - X_s): virtual space of each spin raised
+                eye = torch.eye(fo.shape[-1], dtype=fo.dtype, device=fo.device)
+                fo = fo + self.level_shift * (eye.unsqueeze(0) - st["dmo"])
+            front = self._udensities(st, fo)
+        saved_count = st["diis"].count
+        e_prev = st["e_tot"]
+        ctx = self._ulaunch(st, front["dm"], front["dmo"], st["cycle"] + 1, front["trs"])
+        nxt = self._ufront(st)
+        ok = self._ufinish(st, ctx, front["shapes"], front["planned"], e_prev)
+        if not ok:
+            # a planned purification had not converged (the spectrum left the planned bounds): roll the DIIS push back and
+            # redo the cycle by diagonalisation, which also refreshes the plans
+            nxt = None
+            self.n_redo = getattr(self, "n_redo", 0) + 1
+            st["diis"].count = saved_count
+            redo = self._udensities(st, front["fo"], allow_plan=False)
+            ctx = self._ulaunch(st, redo["dm"], redo["dmo"], st["cycle"] + 1, redo["trs"])
+            self._ufinish(st, ctx, redo["shapes"], redo["planned"], e_prev)
+        if nxt is not None:
+            st["front"] = nxt
+        st["cycle"] += 1
+        return st
+
+    def _kernel_fast(self, dm0=None):
+        t_start = time.time()
+        mol = self.mol
+        self._setup_once()
+        eng = self.engine
+        L, Li = self._L, self._Linv
+        na, nb = mol.nelec
+        self.nelec = (na, nb)
+        n = eng.nao
+        if dm0 is None:
+            dm0 = self.get_init_guess()
+        dm0 = np.asarray(dm0)
+        if dm0.ndim == 2:
+            ne = max(na + nb, 1)
+            dm0 = np.stack([dm0 * (na / ne), dm0 * (nb / ne)])
+        dm = torch.as_tensor(dm0, dtype=torch.float64, device=eng.device).contiguous()
+        if self._nranks > 1:   # one-off: identical starting density on every rank (see SCF._start)
+            from . import parallel
+            parallel.broadcast0(dm, self._pg)
+        from .scf import DeviceDIIS
+        st = {"nocc": (na, nb), "enuc": mol.energy_nuc(), "cycle": 0, "diis": DeviceDIIS(eng, self.diis_space, nmat=2),
+              "spin": self._spin_states(n), "nvo": max(na * (n - na) + nb * (n - nb), 1), "e_tot": None}
+        dmo0 = torch.stack([L.T @ dm[0] @ L, L.T @ dm[1] @ L])
+        ctx = self._ulaunch(st, dm, dmo0, 0, [None, None])
+        self._ufinish(st, ctx, [None, None], [False, False], None)
+        conv_tol = self.conv_tol
+        conv_tol_grad = self.conv_tol_grad if self.conv_tol_grad is not None else np.sqrt(conv_tol)
+        self._log(4, f"init E= {st['e_tot']:.15g}")
+        self.converged = False
+        t_loop = time.time()
+        while st["cycle"] < self.max_cycle:
+            self._ustep(st)
+            self._log(4, f"cycle= {st['cycle']} E= {st['e_tot']:.15g}  delta_E= {st['de']:.3g}  |g|= {st['gnorm']:.3g}")
+            if abs(st["de"]) < conv_tol and st["gnorm"] < conv_tol_grad:
+                self.converged = True
+                break
+        st.pop("front", None)
+        self.cycles = st["cycle"]
+        self.timing["loop_seconds"] = time.time() - t_loop
+
+        def orbitals(Fx):
+            es, cs = [], []
+            for s_ in range(2):
+                e_, c_ = torch.linalg.eigh(Li @ Fx[s_] @ Li.T)
+                es.append(e_); cs.append(Li.T @ c_)
+            return torch.stack(es), torch.stack(cs)
+
+        F, dm, e_tot = st["F"], st["dm"], st["e_tot"]
+        mo_e, mo_c = orbitals(F)
+        if self.converged and self.conv_check:
+            ca, cb = mo_c[0][:, :na], mo_c[1][:, :nb]
+            dm = torch.stack([ca @ ca.T, cb @ cb.T])
+            F, e_el = self._fock_pair(dm)
+            e_new = float(e_el) + st["enuc"]
+            self._log(4, f"Extra cycle  E= {e_new:.15g}  delta_E= {e_new - e_tot:.3g}")
+            e_tot = e_new
+        self._dm, self._fock = dm, F
+        self.e_tot = e_tot
+        self.mo_energy = mo_e.cpu().numpy()
+        self._seed_plans(mo_e)
+        self.mo_coeff = mo_c.cpu().numpy()
+        occ = np.zeros((2, n))
+        occ[0, :na] = 1.0
+        occ[1, :nb] = 1.0
+        self.mo_occ = occ
+        self.timing["total_seconds"] = time.time() - t_start
+        if self.converged:
+            ss, mult = self.spin_square()
+            self._log(3, f"converged SCF energy = {self.e_tot:.15g}  <S^2> = {ss:.8g}  2S+1 = {mult:.8g}")
+        else:
+            self._log(3, f"SCF not converged.\nSCF energy = {self.e_tot:.15g} after {self.max_cycle} cycles")
+        return self.e_tot
+
+    def _kernel_plain(self, dm0=None, **kw):
         t_start = time.time()
         mol = self.mol
         self._setup_once()
@@ -250,6 +526,7 @@ class UHF(SCF):
         self._dm, self._fock = dm, F
         self.e_tot = e_tot
         self.mo_energy = mo_e.cpu().numpy()
+        self._seed_plans(mo_e)
         self.mo_coeff = mo_c.cpu().numpy()
         occ = np.zeros((2, n))
         occ[0, :na] = 1.0
@@ -262,8 +539,6 @@ class UHF(SCF):
         else:
             self._log(3, f"SCF not converged.\nSCF energy = {self.e_tot:.15g} after {self.max_cycle} cycles")
         return self.e_tot
-
-    scf = kernel
 
     def dip_moment(self, mol=None, dm=None, unit="Debye", verbose=None, **kw):
         if dm is None:

@@ -144,6 +144,10 @@ int mi_diis_dots_dev(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int
  * system is singular).  mi_diis_combine_dev = mi_diis_combine with the coefficients read from device memory. */
 int mi_diis_solve(mi_ctx *ctx, const double *d_part, int m, int slot, int space, double *d_B, double *d_coef, void *stream);
 int mi_diis_combine_dev(mi_ctx *ctx, const double *d_hist, const double *d_coef, int n, double *d_out, void *stream);
+/* The same two with an explicit vector length `len` (doubles per history entry) instead of nao^2: the stacked (F_alpha, F_beta)
+ * pair of UHF / UKS (scf.diis.CDIIS on the spin-stacked Fock matrix, templates/calculate_bde.py:126-128) has len = 2 nao^2. */
+int mi_diis_dots_dev_n(mi_ctx *ctx, const double *d_hist_e, const double *d_e, int n, int64_t len, double *d_out, void *stream);
+int mi_diis_combine_dev_n(mi_ctx *ctx, const double *d_hist, const double *d_coef, int n, int64_t len, double *d_out, void *stream);
 
 
 /* ---- density from the Fock matrix without diagonalisation (row a11) ----------------------------- */

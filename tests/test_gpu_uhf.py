@@ -98,3 +98,36 @@ def test_uhf_sp2_path_matches_diagonalisation():
     assert abs(res["sp2"][0] - res["eigh"][0]) < 1e-8, res
     assert abs(res["sp2"][3] - res["eigh"][3]) < 1e-5
     print("UHF C6H6+ cc-pVTZ:", res)
+
+
+def test_uhf_fast_loop_with_planned_purification_equals_the_plain_loop():
+    """The orthonormal-basis UHF/UKS loop (device-side pair DIIS, planned purification per spin, pipelined step) against the
+    plain loop: benzene cation / cc-pVDZ with the purification forced on (sp2_min_nao = 0).  The first kernel() of an object is
+    cold (plain loop, seeds the plans from its final orbitals), the second runs the fast loop with those plans."""
+    import gpu4pyscf
+    from pyscf import gto
+    from mi355scf import fixtures
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.charge, mol.spin, mol.verbose = fixtures.BENZENE, "cc-pVDZ", 1, 1, 0
+    mol.build()
+    ref = gpu4pyscf.scf.UHF(mol).to_gpu()
+    ref.fast_loop, ref.conv_tol = False, 1e-10
+    e_ref = ref.kernel()
+    assert ref.converged
+    mf = gpu4pyscf.scf.UHF(mol).to_gpu()
+    mf.sp2_min_nao, mf.conv_tol = 0, 1e-10
+    e_cold = mf.kernel()                               # plain loop + plans
+    assert mf.converged and abs(e_cold - e_ref) < 1e-9
+    assert all(sp.vals["_sp2_plan"] is not None for sp in mf._spin_pair)
+    dm = mf.make_rdm1()
+    e_warm = mf.kernel(dm0=dm)                         # fast loop, planned purification of both spins from the first cycle
+    assert mf.converged and abs(e_warm - e_ref) < 1e-9 and mf.cycles <= 4
+    assert abs(mf.spin_square()[0] - ref.spin_square()[0]) < 1e-6
+    ks_ref = gpu4pyscf.dft.UKS(mol).to_gpu()
+    ks_ref.xc, ks_ref.fast_loop, ks_ref.conv_tol = "B3LYP", False, 1e-10
+    ek_ref = ks_ref.kernel()
+    ks = gpu4pyscf.dft.UKS(mol).to_gpu()
+    ks.xc, ks.sp2_min_nao, ks.conv_tol = "B3LYP", 0, 1e-10
+    ks.kernel()
+    ek = ks.kernel(dm0=ks.make_rdm1())
+    assert ks.converged and abs(ek - ek_ref) < 1e-8, (ek, ek_ref)
