@@ -164,6 +164,7 @@ class Engine:
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", device if isinstance(device, int) else device.index)
+        _warm_libraries(self.device, mol.nao)
         self._atm = np.ascontiguousarray(mol._atm, dtype=np.int32)
         self._bas = np.ascontiguousarray(mol._bas, dtype=np.int32)
         self._env = np.ascontiguousarray(mol._env, dtype=np.float64)
@@ -483,6 +484,48 @@ class Engine:
         out = np.zeros(n)
         _check(lib().mi_diis_dots(self._h, hist_e.data_ptr(), e.data_ptr(), n, _dp(out), self._stream()))
         return out
+
+
+_WARM = {"started": False}
+
+
+def _warm_libraries(device, n=32):
+    """First use of rocSOLVER (syevd, potrf), rocBLAS (trsm, small GEMMs) and of the pinned-memory allocator costs ~0.3 s in
+    a fresh process -- more than a whole SCF of a BASELINE config-3 molecule, and the reference's templates start one process
+    per molecule.  The one-off initialisation (library handles, workspaces, the Tensile / rocSOLVER code objects of the n x n
+    shapes the SCF loop uses) is triggered once per process on a helper thread with throw-away n x n inputs while the main
+    thread sets up integrals (the library calls release the GIL); nothing of the calculation depends on it.
+    MI355_NO_WARMUP=1 disables it."""
+    if _WARM["started"] or os.environ.get("MI355_NO_WARMUP"):
+        return
+    _WARM["started"] = True
+    import threading
+
+    def work():
+        try:
+            with torch.cuda.device(device):
+                s = torch.cuda.Stream(device=device)
+                with torch.cuda.stream(s):
+                    n_ = int(max(8, min(n, 1024)))
+                    a = torch.eye(n_, dtype=torch.float64, device=device) * 2.0 + 0.01 / n_
+                    torch.linalg.eigh(a)
+                    r, _ = torch.linalg.cholesky_ex(a)
+                    torch.linalg.solve_triangular(r, a, upper=False)
+                    (a @ a).sum()
+                    torch.addmm(a, a, a, beta=0.5, alpha=0.5)
+                    m_ = min(24, n_)                      # the small factorisation / triangular solve of the low-rank XC densities
+                    r2, _ = torch.linalg.cholesky_ex(a[:m_, :m_].contiguous())
+                    torch.linalg.solve_triangular(r2, a[:m_, :].contiguous(), upper=False)
+                    (a[:, :m_].T @ a)
+                    torch.dot(a[0], a[1])
+                    torch.empty(64, dtype=torch.float64).pin_memory()
+                s.synchronize()
+        except Exception:
+            pass
+
+    t = threading.Thread(target=work, name="mi355scf-warmup", daemon=True)
+    t.start()
+    _WARM["thread"] = t
 
 
 _ENGINES = {}

@@ -481,6 +481,7 @@ class SCF:
         self._sp2_hist_shape = (coef.shape[0], (n + 15) // 16)
         return res[0], tr[:off + 64]   # a view of the ping-pong buffers: consumed by this cycle's Fock build, before the next pass
 
+    sp2_plan_gnorm = 2e-3      # make the purification plan only once the previous cycle's |g| is below this
     sp2_planned_gemm = True   # N > sp2_fused_max: the same planned sequence with one rocBLAS DGEMM (addmm) per pass
 
     def _sp2_plannable(self, n):
@@ -758,9 +759,20 @@ class SCF:
             n = fo.shape[0]
             planned_ok = (use_sp2 and self.sp2_planned and self._sp2_plannable(n) and 0 < nocc < n and not self.level_shift)
             dmo = None
+            # A plan needs spectral bounds, i.e. one diagonalisation (7 ms at N = 264, 40 ms at 573), and holds while HOMO / LUMO
+            # move by less than its margins.  From a superposition-of-atoms guess the spectrum moves more than that in the
+            # first two or three cycles (measured: a plan made at cycle 1 failed its trace check at cycles 2 and 3, each costing
+            # another diagonalisation and a second Fock build), so while the orbital gradient of the previous cycle is above
+            # `sp2_plan_gnorm` the trace-correcting purification runs instead -- it needs no bounds -- and the plan is made once,
+            # when the SCF has settled; warm starts (dm0 from a nearby geometry) plan at their first cycle.
+            early = planned_ok and self._sp2_plan is None and st.get("gnorm", 0.0) > self.sp2_plan_gnorm
             if planned_ok and self._sp2_plan is not None and not st.get("_redo"):
                 dmo, tr_dev = self._sp2_planned_async(fo, nocc)
                 self._sp2_planned_pass = True
+            elif early and self._sp2_validated and not st.get("_redo"):
+                dmo, tr_dev = self._sp2_fused_async(fo, nocc)
+            elif early:
+                dmo = self._density_sp2(fo, nocc, orth=True)
             elif planned_ok:
                 # no plan yet: diagonalise below, which also yields the bounds for one.  (Bounds from ~130 Lanczos steps on the
                 # projected Fock matrix instead -- HOMO, LUMO with residual bounds, Gershgorin outside -- were tried: as torch
