@@ -1915,6 +1915,13 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     {
         TileArena &pk = g_arena[c->device & 15];
         if (pk.ptr && pk.doubles >= c->tile_alloc && pk.doubles <= c->tile_alloc + c->tile_alloc / 4 + (1 << 20)) c->tile_alloc = pk.doubles;
+        else {
+            // a fresh allocation: 2 % of head room, so that the next geometry of an optimisation (a few more tiles survive the
+            // Schwarz test) still fits the parked store -- re-allocating 103 GB took 6 s on a box of the pool (measured in a
+            // geometry step of ibuprofen/def2-TZVP: 7.6 s instead of 1.9 s)
+            const int64_t padded = c->tile_alloc + c->tile_alloc / 50;
+            if ((size_t)padded * 8 + ((size_t)1 << 30) <= freeb) c->tile_alloc = padded;
+        }
     }
     if (arena_take(c->device, c->tile_alloc, &c->d_tiles)) return -1;
     HIPCHK(hipMemsetAsync(c->d_tiles, 0, sizeof(double) * std::max<int64_t>(off, 1), st));

@@ -212,9 +212,11 @@ def optimize(mf, maxsteps=100, callback=None, coordsys="internal", **kw):
     optimised geometry.  `coordsys="internal"` (default; redundant primitive internals, Cartesian fallback) or
     "cart"."""
     gs = mf.nuc_grad_method().as_scanner()
-    # forces inside the optimisation loop: derivative quartets screened at 1e-11 instead of 1e-13 (forces change by ~2e-7
-    # Ha/Bohr, three orders below the convergence thresholds; ibuprofen/def2-TZVP gradient 2.2 -> 1.9 s)
-    gs.grad_dtol = kw.pop("grad_dtol", 1e-11)
+    # forces inside the optimisation loop: derivative quartets screened at 1e-10 instead of 1e-13.  Measured on ibuprofen /
+    # def2-TZVP with one density (tools/eri_bench.py, GRAD_DTOLS): 1e-13 1.30 s; 1e-11 1.03 s, forces change by 1.5e-7 Ha/Bohr;
+    # 1e-10 0.87 s, 1.3e-6 (0.3 % of geomeTRIC's 4.5e-4 max-gradient criterion); 1e-9 0.72 s, 1.5e-5 (too close to it).
+    # `optimize(mf, grad_dtol=...)` overrides; single gradients (`mf.nuc_grad_method().kernel()`) keep 1e-13.
+    gs.grad_dtol = kw.pop("grad_dtol", 1e-10)
     mol = mf.mol
     log = lambda msg: mf._log(3, msg)
     log("Step    Energy (Ha)        dE         RMS grad    max grad    RMS disp(A)  max disp(A)")

@@ -39,6 +39,17 @@ if "--grad" in sys.argv:   # derivative-ERI contraction with a converged RHF den
             mf.engine.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     D = torch.as_tensor(mf.make_rdm1(), device="cuda")
     g = torch.zeros(mol.natm, 3, dtype=torch.float64, device="cuda")
+    if os.environ.get("GRAD_DTOLS"):   # screening sweep on ONE density: time and deviation from the tightest threshold
+        ref = None
+        for dt in [float(x) for x in os.environ["GRAD_DTOLS"].split(",")]:
+            mf.engine.set_option("grad_dtol", dt)
+            g.zero_()
+            torch.cuda.synchronize(); t0 = time.time(); mf.engine.grad_eri(D, 1.0, g); torch.cuda.synchronize()
+            dtm = time.time() - t0
+            if ref is None:
+                ref = g.clone()
+            print(json.dumps(dict(grad_dtol=dt, grad_eri_s=round(dtm, 3), max_dev_from_first=float((g - ref).abs().max()))), flush=True)
+        sys.exit(0)
     for hyb in (1.0, 0.2):
         g.zero_()
         t0 = time.time(); mf.engine.grad_eri(D, hyb, g); torch.cuda.synchronize()

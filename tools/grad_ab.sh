@@ -1,2 +1,2 @@
 #!/bin/bash
-for o in "grad_nw=1" "grad_nw=2" "grad_nw=4" "grad_nw=1"; do echo "$o"; ERI_OPTS="$o" python tools/eri_bench.py ibuprofen def2-TZVP --grad --quiet 2>&1 | grep grad_eri_s; done
+for o in "grad_dtol=1e-13" "grad_dtol=1e-11" "grad_dtol=1e-10" "grad_dtol=1e-9" "grad_dtol=1e-8"; do echo "$o"; ERI_OPTS="$o" python tools/eri_bench.py ibuprofen def2-TZVP --grad --quiet 2>&1 | grep grad_eri_s; done
