@@ -201,7 +201,7 @@ def main():
     direct_mode = mf._stream_groups > 1
     roof = None
     if not direct_mode:
-        ms = mf.engine.time_jk_kernel(st["dm"], reps=50)
+        ms = mf.engine.time_jk_kernel(st["dm"], reps=500)   # ~0.4 s of back-to-back launches: a stable average on a part whose clocks wander
         alg_bytes = 8.0 * stats["n_unique_eri"] + 24.0 * n * n
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         traffic, source = pmc_traffic(label, alg_bytes) if world == 1 else (None, None)
@@ -216,7 +216,7 @@ def main():
     if world == 1 and not args.no_extra and not direct_mode:
         def leg(engine, nao, est, dm, lab, variants):
             for wj, wk, name, nmat in variants:
-                t = engine.time_jk_kernel(dm, reps=30, with_j=wj, with_k=wk)
+                t = engine.time_jk_kernel(dm, reps=200, with_j=wj, with_k=wk)
                 b = 8.0 * est["n_unique_eri"] + 8.0 * nmat * nao * nao
                 tr, src = pmc_traffic(lab, b, name)
                 more.append({"workload": lab, "variant": name, "ms_per_launch": t, "algorithmic_bytes": b, "traffic": tr, "traffic_source": src,
