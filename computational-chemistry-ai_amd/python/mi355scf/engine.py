@@ -526,6 +526,8 @@ def _warm_libraries(device, n=32):
     t = threading.Thread(target=work, name="mi355scf-warmup", daemon=True)
     t.start()
     _WARM["thread"] = t
+    import atexit
+    atexit.register(lambda: t.join(timeout=10.0))   # never tear the interpreter down under a HIP call of the helper thread
 
 
 _ENGINES = {}
