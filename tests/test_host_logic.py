@@ -238,3 +238,34 @@ def test_diffuse_pople_sets():
     m = Mole(atom=w, basis="6-31+g*", verbose=0).build()
     exps = sorted({float(m._env[m._bas[i, 5]]) for i in range(m.nbas) if m._bas[i, 2] == 1})
     assert abs(exps[0] - 0.0845) < 1e-12                                     # the diffuse sp exponent of oxygen
+
+
+def test_planned_purification_reaches_the_projector_in_about_twenty_quadratics():
+    """`sp2plan.plan` (host logic of row a11): the planned sequence of folded quadratics applied in numpy to a matrix with a
+    molecule-like spectrum (cores at -20, valence to -0.33, virtuals from +0.14 to +40) gives the aufbau projector of `eigh` to
+    1e-12 with ~20 matrix products, and fails loudly (no plan) when the bounds leave no gap."""
+    from mi355scf import sp2plan
+    rng = np.random.default_rng(0)
+    n, nocc = 240, 28
+    e = np.concatenate([np.linspace(-20.6, -11.2, 8), np.linspace(-1.5, -0.33, nocc - 8), np.sort(rng.uniform(0.14, 40.0, n - nocc))])
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    F = (Q * e) @ Q.T
+    F = 0.5 * (F + F.T)
+    w, V = np.linalg.eigh(F)
+    P = V[:, :nocc] @ V[:, :nocc].T
+    lo, hi, homo_in, lumo_in = sp2plan.bounds_from_spectrum(w, nocc, 0.15, 2.0)
+    assert lo < w[0] and hi > w[-1] and w[nocc - 1] < homo_in < lumo_in < w[nocc]
+    coef = sp2plan.plan(lo, hi, homo_in, lumo_in)
+    assert coef is not None and 12 <= coef.shape[0] - 1 <= 24
+    X = coef[0, 1] * F + coef[0, 2] * np.eye(n)
+    for a, b, c in coef[1:]:
+        X = a * (X @ X) + b * X + c * np.eye(n)
+    assert np.abs(X - P).max() < 1e-12 and abs(np.trace(X) - nocc) < 1e-10 and abs(np.trace(X) - np.sum(X * X)) < 1e-10
+    # the spectrum may move inside the margins without breaking the plan ...
+    F2 = (Q * (e + np.where(np.arange(n) < nocc, 0.1, -0.1))) @ Q.T
+    X = coef[0, 1] * F2 + coef[0, 2] * np.eye(n)
+    for a, b, c in coef[1:]:
+        X = a * (X @ X) + b * X + c * np.eye(n)
+    assert np.abs(X - P).max() < 1e-10
+    # ... and bounds without a gap give no plan
+    assert sp2plan.plan(lo, hi, 0.2, 0.1) is None
