@@ -25,7 +25,8 @@
 #include "../../include/mi355scf.h"
 #include "rys_tables.h"
 
-#define LMAX 3
+#define LMAX 4      /* g shells: auxiliary (density-fitting) contexts only; orbital shells stop at f (LMAX_1E) */
+#define LMAX_1E 3   /* one-electron / AO-value kernels: their per-thread blocks are sized for l <= f */
 #define NPC ((LMAX + 1) * (LMAX + 2) / 2) /* pair classes (la>=lb) */
 #define BLK 8
 #define ATM_SLOTS 6
@@ -491,7 +492,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
 // =================================================================================================
 // One-electron integrals: one thread per shell pair (i >= j)
 // =================================================================================================
-#define NC1 10 /* ncart(LMAX) */
+#define NC1 10 /* ncart(LMAX_1E) */
 
 __device__ inline void cart_pow(int l, int idx, int &x, int &y, int &z)
 {
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(64) void int1e_kernel(Int1eArgs A)
             double P[3], PA[3], PB[3];
             for (int d = 0; d < 3; d++) { P[d] = (a * ra[d] + b * rb[d]) / p; PA[d] = P[d] - ra[d]; PB[d] = P[d] - rb[d]; }
             // 1-D overlaps s[d][i][j], i <= la+1, j <= lb+2
-            double s[3][LMAX + 2][LMAX + 3];
+            double s[3][LMAX_1E + 2][LMAX_1E + 3];
             for (int d = 0; d < 3; d++) {
                 s[d][0][0] = 1.0;
                 for (int i = 0; i <= la; i++)
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(64) void int1e_kernel(Int1eArgs A)
                 double x = p * (PC[0] * PC[0] + PC[1] * PC[1] + PC[2] * PC[2]);
                 for (int r = 0; r < nr; r++) {
                     double u = rys_eval(A.rys, nr, r, x), w = rys_eval(A.rys, nr, nr + r, x);
-                    double g[3][2 * LMAX + 1][LMAX + 1]; // g[d][i][j]
+                    double g[3][2 * LMAX_1E + 1][LMAX_1E + 1]; // g[d][i][j]
                     double b10 = (1.0 - u) * h;
                     for (int d = 0; d < 3; d++) {
                         double c00 = PA[d] - u * PC[d];
@@ -642,8 +643,17 @@ __global__ __launch_bounds__(64) void int1e_kernel(Int1eArgs A)
     }
 }
 
+// orbital paths (one-electron integrals, AO values on the grid, resident ERI tiles and their gradients) stop at f shells
+static int check_orbital_lmax(const mi_ctx *c, const char *who)
+{
+    for (const ShellH &sh : c->shells)
+        if (sh.l > LMAX_1E) return fail("%s: shell with l = %d (orbital shells stop at l = %d; g shells are for auxiliary contexts)", who, sh.l, LMAX_1E);
+    return 0;
+}
+
 extern "C" int mi_int1e(mi_ctx *c, double *d_S, double *d_T, double *d_V, double *d_dip, const double *origin, void *stream)
 {
+    if (c && check_orbital_lmax(c, "mi_int1e")) return -1;
     if (!c) return fail("mi_int1e: null context");
     HIPCHK(hipSetDevice(c->device));
     Int1eArgs A;
@@ -1612,6 +1622,7 @@ extern "C" int mi_plan_shards(int nao, const double *qblk, double tol, int nrank
 
 extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void *stream)
 {
+    if (c && check_orbital_lmax(c, "mi_eri_prepare")) return -1;
     if (!c) return fail("mi_eri_prepare: null context");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("mi_eri_prepare: bad rank/nranks");
     HIPCHK(hipSetDevice(c->device));
@@ -3192,6 +3203,7 @@ __global__ __launch_bounds__(256) void eval_ao_kernel(AoArgs A)
 
 extern "C" int mi_eval_ao(mi_ctx *c, const double *d_coords, int64_t ng, int deriv, double *d_ao, void *stream)
 {
+    if (c && check_orbital_lmax(c, "mi_eval_ao")) return -1;
     if (!c || !d_coords || !d_ao) return fail("mi_eval_ao: null argument");
     HIPCHK(hipSetDevice(c->device));
     AoArgs A;
@@ -4092,7 +4104,7 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(Grad1eArgs A)
             double ex = exp(-mu * (AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2]));
             double P[3], PA[3], PB[3];
             for (int d = 0; d < 3; d++) { P[d] = (a * ra[d] + b * rb[d]) / p; PA[d] = P[d] - ra[d]; PB[d] = P[d] - rb[d]; }
-            double s[3][LMAX + 3][LMAX + 3]; // s[d][i][j], i <= la+1, j <= lb+2
+            double s[3][LMAX_1E + 3][LMAX_1E + 3]; // s[d][i][j], i <= la+1, j <= lb+2
             for (int d = 0; d < 3; d++) {
                 s[d][0][0] = 1.0;
                 for (int i = 0; i <= la; i++) s[d][i + 1][0] = PA[d] * s[d][i][0] + (i > 0 ? i * h * s[d][i - 1][0] : 0.0);
@@ -4142,7 +4154,7 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(Grad1eArgs A)
                 double gc[3] = {0.0, 0.0, 0.0};
                 for (int r = 0; r < nr; r++) {
                     double u = rys_eval(A.rys, nr, r, xarg), w = rys_eval(A.rys, nr, nr + r, xarg);
-                    double g[3][2 * LMAX + 2][LMAX + 1];
+                    double g[3][2 * LMAX_1E + 2][LMAX_1E + 1];
                     double b10 = (1.0 - u) * h;
                     for (int d = 0; d < 3; d++) {
                         double c00 = PA[d] - u * PC[d];
@@ -4182,6 +4194,7 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(Grad1eArgs A)
 
 extern "C" int mi_grad_1e(mi_ctx *c, const double *d_D, const double *d_W, double *d_grad, void *stream)
 {
+    if (c && check_orbital_lmax(c, "mi_grad_1e")) return -1;
     if (!c || !d_D || !d_W || !d_grad) return fail("mi_grad_1e: null argument");
     HIPCHK(hipSetDevice(c->device));
     Grad1eArgs A;

@@ -21,11 +21,11 @@ import torch
 from . import engine as _engine
 from .mole import Mole, split_ghost
 
-LMAX_AUX = 3
+LMAX_AUX = 4
 
 
 def even_tempered_aux(mol, beta=2.0):
-    """{element: PySCF-format shell list}: for each l_aux <= min(2 l_max, 3) exponents alpha_k = a_min beta^k covering
+    """{element: PySCF-format shell list}: for each l_aux <= min(2 l_max, LMAX_AUX = 4) exponents alpha_k = a_min beta^k covering
     [a_i + a_j] over the orbital primitive pairs with l_i + l_j >= l_aux (|l_i - l_j| <= l_aux)."""
     out = {}
     bas, env = mol._bas, mol._env

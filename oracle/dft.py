@@ -109,7 +109,7 @@ def build_grids(mol, level=3):
 
 # ---------------------------------------------------------------------------------------------
 def _c2s(l):
-    out = np.zeros((10, 7))
+    out = np.zeros((15, 9))      # [NCART_MAX][NSPH_MAX] of oracle.c
     orc.lib().orc_c2s.restype = None
     orc.lib().orc_c2s(ctypes.c_int(l), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     return out[:(l + 1) * (l + 2) // 2, :2 * l + 1]

@@ -45,11 +45,11 @@
 #define PTR_EXP 5
 #define PTR_COEFF 6
 
-#define LMAX 3            /* f */
+#define LMAX 4            /* g (auxiliary density-fitting shells; orbital tables stop at f) */
 #define LMAX1 (LMAX + 1)
-#define NCART_MAX 10
-#define NSPH_MAX 7
-#define TMAX (4 * LMAX + 1) /* Hermite order range for an ERI: 0..12 */
+#define NCART_MAX 15
+#define NSPH_MAX 9
+#define TMAX (4 * LMAX + 1) /* Hermite order range for an ERI: 0..16 */
 
 static const double PI = 3.14159265358979323846;
 
@@ -91,6 +91,25 @@ static void c2s_matrix(int l, double c[NCART_MAX][NSPH_MAX])
         c[5][4] = 4 * 0.4570457994644658; c[0][4] = -0.4570457994644658; c[3][4] = -0.4570457994644658;
         c[2][5] = 1.445305721320277;  c[7][5] = -1.445305721320277;                  /* z(x2-y2) */
         c[0][6] = 0.5900435899266435; c[3][6] = -3 * 0.5900435899266435;             /* x3 - 3xy2 */
+        return;
+    }
+    if (l == 4) {
+        /* xxxx0 xxxy1 xxxz2 xxyy3 xxyz4 xxzz5 xyyy6 xyyz7 xyzz8 xzzz9 yyyy10 yyyz11 yyzz12 yzzz13 zzzz14;
+         * real solid harmonics of the standard tables (r^2 = x^2 + y^2 + z^2 expanded):
+         *  m=-4: A xy(x2-y2)   m=-3: B yz(3x2-y2)   m=-2: C xy(7z2-r2)   m=-1: D yz(7z2-3r2)   m=0: E (35z4-30z2r2+3r4)
+         *  m=+1: D xz(7z2-3r2) m=+2: F (x2-y2)(7z2-r2)   m=+3: B xz(x2-3y2)   m=+4: G (x4-6x2y2+y4) */
+        const double A = 0.75 * sqrt(35.0 / PI), B = 0.75 * sqrt(35.0 / (2.0 * PI)), C = 0.75 * sqrt(5.0 / PI),
+                     D = 0.75 * sqrt(5.0 / (2.0 * PI)), E = 0.1875 * sqrt(1.0 / PI), F = 0.375 * sqrt(5.0 / PI),
+                     G = 0.1875 * sqrt(35.0 / PI);
+        c[1][0] = A; c[6][0] = -A;
+        c[4][1] = 3 * B; c[11][1] = -B;
+        c[8][2] = 6 * C; c[1][2] = -C; c[6][2] = -C;
+        c[13][3] = 4 * D; c[4][3] = -3 * D; c[11][3] = -3 * D;
+        c[0][4] = 3 * E; c[10][4] = 3 * E; c[14][4] = 8 * E; c[3][4] = 6 * E; c[5][4] = -24 * E; c[12][4] = -24 * E;
+        c[9][5] = 4 * D; c[2][5] = -3 * D; c[7][5] = -3 * D;
+        c[0][6] = -F; c[10][6] = F; c[5][6] = 6 * F; c[12][6] = -6 * F;
+        c[2][7] = B; c[7][7] = -3 * B;
+        c[0][8] = G; c[3][8] = -6 * G; c[10][8] = G;
         return;
     }
 }
@@ -864,7 +883,7 @@ int orc_num_threads(void)
 #endif
 }
 
-/* c2s table for tests and the numpy AO evaluator: out[10][7] */
+/* c2s table for tests and the numpy AO evaluator: out[NCART_MAX = 15][NSPH_MAX = 9] */
 void orc_c2s(int l, double *out)
 {
     double c[NCART_MAX][NSPH_MAX];

@@ -41,7 +41,9 @@ def test_df_integrals_and_jk_match_oracle(name, basis):
 def test_density_fitted_scf_energy_close_to_exact():
     from mi355scf import fixtures
     from pyscf import gto, scf, dft
-    for atom, basis, tol in ((MOLECULES["h2co"], "6-31G(d)", 2e-4), (fixtures.BENZENE, "cc-pVDZ", 1e-3)):
+    # generated even-tempered auxiliary basis with l_aux <= 4 (g): measured 3.8e-5 / 7.0e-5 Ha (tools/df_beta.py); 1e-4 is what
+    # VERDICT r01 item 7 asked for (with l_aux <= 3 the error saturated at 2e-4 whatever the even-tempered ratio)
+    for atom, basis, tol in ((MOLECULES["h2co"], "6-31G(d)", 1e-4), (fixtures.BENZENE, "cc-pVDZ", 1e-4)):
         mol = gto.Mole()
         mol.atom, mol.basis, mol.verbose = atom, basis, 0
         mol.build()
