@@ -310,6 +310,7 @@ struct mi_ctx {
     int opt_xf_mfma_min = 300; // transform kernel: MFMA tiles only when the spherical block has at least this many elements
     double opt_tpq_maxprim = 32.0; // thread-per-quartet kernels only when the mean primitive quartets per shell quartet stay below this
     int opt_eri_tpq = 1;     // thread-per-quartet fused ERI kernels for the low angular classes (0: wave-per-quartet pair everywhere)
+    int opt_jk_pair = -1;    // n_dm = 2: one pass with two waves per work item (-1: for stores > 16 GB, 0: one pass per density, 1: always)
     int opt_tri_tiles = 1;   // block-diagonal tiles store triangular rows (0: the full-row layout of round 1); next mi_eri_prepare
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
@@ -397,9 +398,10 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
     for (int n = 1; n <= RYS_NMAX; n++) c->rys.off[n] = RYS_OFFSET_H[n];
     // J/K buffers
     size_t pp = (size_t)c->ldp * c->ldp;
-    HIPCHK(hipMalloc(&c->d_Dpad, sizeof(double) * pp));
-    HIPCHK(hipMalloc(&c->d_Jacc, sizeof(double) * pp));
-    HIPCHK(hipMalloc(&c->d_Kacc, sizeof(double) * pp));
+    // two of each: the spin pair of UHF / UKS is digested by one launch (jk_tiles_pair_kernel)
+    HIPCHK(hipMalloc(&c->d_Dpad, sizeof(double) * 2 * pp));
+    HIPCHK(hipMalloc(&c->d_Jacc, sizeof(double) * 2 * pp));
+    HIPCHK(hipMalloc(&c->d_Kacc, sizeof(double) * 2 * pp));
     HIPCHK(hipMalloc(&c->d_red, sizeof(double) * 4096));
     *out = c;
     return 0;
@@ -480,6 +482,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_nt") c->opt_jk_nt = (int)value;
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
+    else if (k == "jk_pair") c->opt_jk_pair = (int)value;
     else if (k == "tri_tiles") c->opt_tri_tiles = (int)value;       // takes effect at the next mi_eri_prepare
     else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;
     else if (k == "tpq_maxprim") c->opt_tpq_maxprim = value;
@@ -2254,6 +2257,8 @@ struct JkArgs {
     int ld, nao;
     int n_cached;            // leading work items read with the default cache policy (kept in the Infinity Cache)
     int tri;                 // triangular rows in block-diagonal tiles (tile geometry)
+    size_t pair_stride;      // jk_tiles_pair_kernel: doubles between the two padded densities / accumulator sets
+    int pair_sync;           // barrier per tile between the two waves
 };
 
 __device__ inline double red_select_xor(double a, double b, bool hi, int mask)
@@ -2350,10 +2355,10 @@ __device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, 
     }
 }
 
-template <bool WITH_J, bool WITH_K, bool NT>
+template <bool WITH_J, bool WITH_K, bool NT, bool PAIR = false>
 __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int i = lane >> 3, k = lane & 7;
     const MI_CONST_AS int *tile_I = as_const(A.tile_I);
     const MI_CONST_AS int64_t *tile_off = as_const(A.tile_off);
@@ -2390,6 +2395,7 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
             const int I0 = I_next * BLK;
             const int64_t toff = off_next;
             if (R.count > 1) { I_next = tile_I[R.first + 1]; off_next = tile_off[R.first + 1]; }
+            if (PAIR && A.pair_sync) __syncthreads();   // the two waves of a pair stay within one tile of each other: the second reader hits L2
             jk_digest_tile<WITH_J, WITH_K, NT, true, true>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
             t = 1;
         }
@@ -2397,6 +2403,7 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
             const int I0 = I_next * BLK;
             const int64_t toff = off_next;
             if (t + 1 < R.count) { I_next = tile_I[R.first + t + 1]; off_next = tile_off[R.first + t + 1]; }
+            if (PAIR && A.pair_sync) __syncthreads();   // the two waves of a pair stay within one tile of each other: the second reader hits L2
             jk_digest_tile<WITH_J, WITH_K, NT, false, true>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
         }
     } else {
@@ -2404,6 +2411,7 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
             const int I0 = I_next * BLK;
             const int64_t toff = off_next;
             if (R.count > 1) { I_next = tile_I[R.first + 1]; off_next = tile_off[R.first + 1]; }
+            if (PAIR && A.pair_sync) __syncthreads();   // the two waves of a pair stay within one tile of each other: the second reader hits L2
             jk_digest_tile<WITH_J, WITH_K, NT, true, false>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
             t = 1;
         }
@@ -2411,6 +2419,7 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
             const int I0 = I_next * BLK;
             const int64_t toff = off_next;
             if (t + 1 < R.count) { I_next = tile_I[R.first + t + 1]; off_next = tile_off[R.first + t + 1]; }
+            if (PAIR && A.pair_sync) __syncthreads();   // the two waves of a pair stay within one tile of each other: the second reader hits L2
             jk_digest_tile<WITH_J, WITH_K, NT, false, false>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
         }
     }
@@ -2451,6 +2460,28 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
     }
 }
 
+
+// Two densities in ONE pass over the tiles (the spin pair of UHF / UKS).  A single wave cannot hold two sets of
+// run-wide accumulators (2 x 64 K_JL + ... : the compiler spills, section 3.1 of DESIGN.md), so a workgroup of TWO waves
+// digests one work item: wave 0 with density / accumulators 0, wave 1 with set 1, each with the register budget of the
+// single-density kernel, on two SIMDs of one CU.  Both read the same tiles; a barrier per tile keeps them within one tile of
+// each other, so the second reader of a 16-byte chunk finds it in L2 (default cache policy: no nontemporal hint here) and
+// HBM is read once for both densities.
+template <bool WITH_J, bool WITH_K, bool NT>
+__global__ __launch_bounds__(128) void jk_tiles_pair_kernel(JkArgs A)
+{
+    const int wave = threadIdx.x >> 6;
+    JkArgs B = A;
+    B.D = A.D + wave * A.pair_stride;
+    B.Jacc = A.Jacc + wave * A.pair_stride;
+    B.Kacc = A.Kacc + wave * A.pair_stride;
+    const MI_CONST_AS int *wave_seg = as_const(A.wave_seg);
+    const int seg_end = wave_seg[blockIdx.x + 1];
+    for (int seg = wave_seg[blockIdx.x]; seg < seg_end; seg++) {
+        if (NT && seg < A.n_cached) jk_segment<WITH_J, WITH_K, false, true>(B, seg);
+        else jk_segment<WITH_J, WITH_K, NT, true>(B, seg);
+    }
+}
 
 // Software-pipelined variant for the K-carrying builds (one wave per SIMD, so a wave has to overlap its own
 // loads with its own arithmetic): a tile is digested as two halves of 4 j-rows (16 double2 chunks per lane
@@ -2715,7 +2746,7 @@ __global__ void finalize_jk_kernel(const double *Jacc, const double *Kacc, doubl
 static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
 {
     JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao,
-             c->n_jk_cached, c->tri};
+             c->n_jk_cached, c->tri, (size_t)c->ldp * c->ldp, 0};
     if (c->n_tiles == 0) return 0;
     dim3 g(A.nruns), b(64);
     // nontemporal loads only when the tensor cannot stay in the 256 MiB Infinity Cache between SCF cycles
@@ -2742,6 +2773,29 @@ extern "C" int mi_build_jk(mi_ctx *c, const double *d_D, int n_dm, double *d_J, 
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     size_t nn = (size_t)c->nao * c->nao, pp = (size_t)c->ldp * c->ldp;
+    // one pass for the pair when it pays: measured -9 % on the 103 GB ibuprofen tensor (UHF cycle 38 -> 34.5 ms), -3 % ... +60 %
+    // (erratic) on the 4.9 GB benzene/cc-pVTZ tensor -- so by default only for stores beyond 16 GB (jk_pair = 1: always, 0: never)
+    const bool use_pair = c->opt_jk_pair > 0 || (c->opt_jk_pair < 0 && c->tile_doubles * 8 > ((int64_t)16 << 30));
+    if (n_dm == 2 && use_pair && c->n_tiles > 0) {
+        for (int m = 0; m < 2; m++)
+            hipLaunchKernelGGL(pad_density_clear_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D + m * nn, c->d_Dpad + m * pp,
+                               d_J ? c->d_Jacc + m * pp : nullptr, d_K ? c->d_Kacc + m * pp : nullptr, c->nao, c->ldp);
+        JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao,
+                 c->n_jk_cached, c->tri, pp, 1};
+        dim3 g(A.nruns), b(128);
+        // same cache policy as the single-density kernel: nontemporal stream + default-policy prefix for tensors beyond the
+        // Infinity Cache (an all-default-policy stream of 4.9 GB made the launch time erratic: 1.65 ... 2.75 ms)
+        const bool nt = c->opt_jk_nt != 0 && (c->opt_jk_nt > 1 || c->tile_doubles * 8 > ((int64_t)256 << 20));
+        if (d_J && d_K) { if (nt) hipLaunchKernelGGL((jk_tiles_pair_kernel<true, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_pair_kernel<true, true, false>), g, b, 0, st, A); }
+        else if (d_J) { if (nt) hipLaunchKernelGGL((jk_tiles_pair_kernel<true, false, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_pair_kernel<true, false, false>), g, b, 0, st, A); }
+        else { if (nt) hipLaunchKernelGGL((jk_tiles_pair_kernel<false, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_pair_kernel<false, true, false>), g, b, 0, st, A); }
+        HIPCHK(hipGetLastError());
+        for (int m = 0; m < 2; m++)
+            hipLaunchKernelGGL(finalize_jk_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, c->d_Jacc + m * pp, c->d_Kacc + m * pp,
+                               d_J ? d_J + m * nn : nullptr, d_K ? d_K + m * nn : nullptr, c->nao, c->ldp);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     for (int m = 0; m < n_dm; m++) {
         hipLaunchKernelGGL(pad_density_clear_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D + m * nn, c->d_Dpad,
                            d_J ? c->d_Jacc : nullptr, d_K ? c->d_Kacc : nullptr, c->nao, c->ldp);

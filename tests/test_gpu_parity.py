@@ -103,3 +103,25 @@ def test_against_committed_golden_vectors():
     n, exc, vxc, hyb = mf.nr_rks(torch.as_tensor(g["Docc"], device=eng.device))
     assert abs(float(n) - float(g["nelec"])) < 1e-9 and abs(float(exc) - float(g["exc"])) < 1e-9
     assert np.abs(vxc.cpu().numpy() - g["vxc"]).max() < 1e-9 and hyb == float(g["hyb"])
+
+
+@pytest.mark.parametrize("name,basis", [("h2o", "cc-pvtz"), ("ch4", "cc-pvdz")])
+def test_pair_kernel_two_densities_in_one_pass_equals_two_passes(name, basis):
+    """`mi_build_jk(n_dm = 2)` through `jk_tiles_pair_kernel` (two waves per work item, one per density; default for stores beyond
+    16 GB, forced here with `jk_pair = 1`) against one pass per density, J+K, J-only and K-only: 1e-11 (ragged last blocks included:
+    N = 58 and N = 34 are not multiples of 8)."""
+    import torch
+    from mi355scf.engine import Engine
+    mol = _mol(name, basis)
+    eng = Engine(mol)
+    eng.prepare_eri(1e-13)
+    n = mol.nao
+    D2 = torch.as_tensor(np.stack([_sym_density(n, 1), _sym_density(n, 2)]), device="cuda")
+    eng.set_option("jk_pair", 0)
+    Jr, Kr = eng.get_jk(D2)
+    eng.set_option("jk_pair", 1)
+    J, K = eng.get_jk(D2)
+    assert float((J - Jr).abs().max()) < 1e-11 and float((K - Kr).abs().max()) < 1e-11
+    Jj, _ = eng.get_jk(D2, with_k=False)
+    _, Kk = eng.get_jk(D2, with_j=False)
+    assert float((Jj - Jr).abs().max()) < 1e-11 and float((Kk - Kr).abs().max()) < 1e-11

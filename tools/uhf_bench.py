@@ -26,6 +26,15 @@ for i in range(3):
     torch.cuda.synchronize()
     print(f"same object, call {i}: E = {e:.10f} cycles {mfw.cycles} loop {mfw.timing['loop_seconds']:.4f} s = {mfw.timing['loop_seconds'] / max(mfw.cycles, 1) * 1e3:.2f} ms/cycle eigh {getattr(mfw, 'n_eigh', 0)} redo {getattr(mfw, 'n_redo', 0)}", flush=True)
 eng = mfw.engine
+for pair in (0, 1, 0, 1):
+    eng.set_option('jk_pair', pair)
+    mfp = UKS(mol) if xc else UHF(mol)
+    if xc:
+        mfp.xc = xc
+    mfp._eng = eng; mfp.fast_loop = False; mfp.conv_tol = 1e-9
+    e = mfp.kernel()
+    print(f'jk_pair={pair}: E = {e:.10f} cycles {mfp.cycles} {mfp.timing["loop_seconds"] / max(mfp.cycles, 1) * 1e3:.2f} ms/cycle', flush=True)
+eng.set_option('jk_pair', 1)
 for fast in (True, False, True):
     mf = UKS(mol) if xc else UHF(mol)
     if xc:
