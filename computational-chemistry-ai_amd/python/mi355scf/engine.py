@@ -164,7 +164,7 @@ class Engine:
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", device if isinstance(device, int) else device.index)
-        _warm_libraries(self.device, mol.nao)
+        _warm_libraries(self.device, mol.nao, max(1, mol.nelectron // 2))
         self._atm = np.ascontiguousarray(mol._atm, dtype=np.int32)
         self._bas = np.ascontiguousarray(mol._bas, dtype=np.int32)
         self._env = np.ascontiguousarray(mol._env, dtype=np.float64)
@@ -489,7 +489,7 @@ class Engine:
 _WARM = {"started": False}
 
 
-def _warm_libraries(device, n=32):
+def _warm_libraries(device, n=32, nocc=24):
     """First use of rocSOLVER (syevd, potrf), rocBLAS (trsm, small GEMMs) and of the pinned-memory allocator costs ~0.3 s in
     a fresh process -- more than a whole SCF of a BASELINE config-3 molecule, and the reference's templates start one process
     per molecule.  The one-off initialisation (library handles, workspaces, the Tensile / rocSOLVER code objects of the n x n
@@ -513,11 +513,19 @@ def _warm_libraries(device, n=32):
                     torch.linalg.solve_triangular(r, a, upper=False)
                     (a @ a).sum()
                     torch.addmm(a, a, a, beta=0.5, alpha=0.5)
-                    m_ = min(24, n_)                      # the small factorisation / triangular solve of the low-rank XC densities
+                    m_ = int(max(1, min(nocc, n_)))        # the n_occ-sized factorisation / products of the low-rank XC densities
                     r2, _ = torch.linalg.cholesky_ex(a[:m_, :m_].contiguous())
                     torch.linalg.solve_triangular(r2, a[:m_, :].contiguous(), upper=False)
                     (a[:, :m_].T @ a)
+                    w_ = a @ a[:, :m_]
+                    (a[:, :m_].T @ w_)
                     torch.dot(a[0], a[1])
+                    # element-wise / gather kernels of torch are loaded lazily too (first torch.cat: 17 ms)
+                    torch.cat([a[0], a[1], a[2, :2]])
+                    torch.stack([torch.trace(a), torch.sum(a * a)])
+                    a.diagonal().add_(0.0)
+                    (a + a.T).mul_(0.5)
+                    torch.where(torch.isfinite(a).all(), a, a)
                     torch.empty(64, dtype=torch.float64).pin_memory()
                 s.synchronize()
         except Exception:

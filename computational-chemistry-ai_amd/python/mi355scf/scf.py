@@ -482,6 +482,12 @@ class SCF:
         return res[0], tr[:off + 64]   # a view of the ping-pong buffers: consumed by this cycle's Fock build, before the next pass
 
     sp2_plan_gnorm = 2e-3      # make the purification plan only once the previous cycle's |g| is below this
+    # A diagonalisation made only to obtain the plan's bounds (7 ms at N = 264, 40 ms at 573) is never earned back inside one
+    # SCF: the planned path saves 0.3 ms per cycle at N = 264 (0.5 ms at 573).  So by default a cold object runs the
+    # trace-correcting purification throughout; the final diagonalisation of kernel() (needed for mo_energy anyway) seeds the
+    # plan, and every later kernel() of the object -- geometry steps, scans, restarts -- is planned and pipelined from its first
+    # cycle.  True: also plan inside the first SCF, once it has settled (long SCFs).
+    sp2_plan_inloop = False
     sp2_planned_gemm = True   # N > sp2_fused_max: the same planned sequence with one rocBLAS DGEMM (addmm) per pass
 
     def _sp2_plannable(self, n):
@@ -765,12 +771,16 @@ class SCF:
             # another diagonalisation and a second Fock build), so while the orbital gradient of the previous cycle is above
             # `sp2_plan_gnorm` the trace-correcting purification runs instead -- it needs no bounds -- and the plan is made once,
             # when the SCF has settled; warm starts (dm0 from a nearby geometry) plan at their first cycle.
-            early = planned_ok and self._sp2_plan is None and st.get("gnorm", 0.0) > self.sp2_plan_gnorm
+            early = planned_ok and self._sp2_plan is None and (st.get("gnorm", 0.0) > self.sp2_plan_gnorm or not self.sp2_plan_inloop)
             if planned_ok and self._sp2_plan is not None and not st.get("_redo"):
                 dmo, tr_dev = self._sp2_planned_async(fo, nocc)
                 self._sp2_planned_pass = True
+            elif early and st.get("gnorm", 0.0) > self.sp2_plan_gnorm:
+                # checked purification (validated on the host inside, iteration count adapted there): while the spectrum still
+                # moves from cycle to cycle the optimistic variant would guess the count wrong and cost a redo cycle
+                dmo = self._density_sp2(fo, nocc, orth=True)
             elif early and self._sp2_validated and not st.get("_redo"):
-                dmo, tr_dev = self._sp2_fused_async(fo, nocc)
+                dmo, tr_dev = self._sp2_fused_async(fo, nocc)     # settled, but no plan on this object yet (see sp2_plan_inloop)
             elif early:
                 dmo = self._density_sp2(fo, nocc, orth=True)
             elif planned_ok:
@@ -789,8 +799,8 @@ class SCF:
                 co = c[:, :nocc]
                 dmo = 2.0 * co @ co.T
                 st.update(mo_e=e, mo_c=Li.T @ c)
-                if planned_ok:
-                    self._sp2_replan(e, nocc)
+                if planned_ok or (want_mo and self.eig_method == "sp2" and not self.level_shift):
+                    self._sp2_replan(e, nocc)        # (final cycle: the orbital energies seed the plan of the NEXT kernel())
             else:
                 st.pop("mo_e", None)
             dm = Li.T @ dmo @ Li
@@ -849,6 +859,8 @@ class SCF:
         if "mo_e" not in st:  # not converged (or max_cycle == 0): orbitals of the last Fock matrix
             e_, c_ = torch.linalg.eigh(st["fo"])
             st["mo_e"], st["mo_c"] = e_, self._Linv.T @ c_
+            if self.eig_method == "sp2" and not self.level_shift:
+                self._sp2_replan(e_, st["nocc"])
         self._dm, self._vhf = st["dm"], st["fock"] - self._h1
         self.e_tot = float(st["e_tot"])
         self.mo_energy = st["mo_e"].cpu().numpy()
