@@ -142,6 +142,7 @@ class RKS(RHF):
         return hyb
 
     xc_lowrank = True   # inside the SCF loop: rho from occupied-orbital values (D = Z Z^T) instead of D.ao
+    xc_lowrank_min_nao = 128   # below this the dozen small launches of the factorisation cost more than the D.ao GEMM (CH3/cc-pVTZ UKS: 2.9 -> 3.4 ms)
 
     def _occ_factor(self, dm):
         """Z^T [n_occ, nao] with D = Z Z^T when the SCF step declared `dm` a closed-shell projector density (`_xc_projector`:
@@ -153,27 +154,34 @@ class RKS(RHF):
         if not self.xc_lowrank or proj is None or proj[0] is not dm:
             return None
         _dm, dmo, nocc = proj
+        return self._lowrank_factor(dmo, nocc, "rks")
+
+    def _lowrank_factor(self, dmo, nocc, key):
+        """Z^T [nocc, nao] with L^-T dmo L^-1 = Z Z^T for a positive semidefinite orthonormal-basis matrix `dmo` of rank nocc
+        (2 X for RKS, the spin projectors X_s for UKS); `key` names the warm-start state (one per spin channel)."""
         n = dmo.shape[0]
-        if not (0 < nocc < n // 2):
+        if not (0 < nocc < n // 2) or n < self.xc_lowrank_min_nao:
             return None
-        G0 = getattr(self, "_nystrom_G0", None)
+        st = self.__dict__.setdefault("_nystrom", {})
+        G0 = st.get((key, "G0"))
         if G0 is None or G0.shape != (n, nocc) or G0.device != dmo.device:
             g = torch.Generator(device="cpu").manual_seed(20251004)
-            G0 = self._nystrom_G0 = torch.randn(n, nocc, generator=g, dtype=torch.float64).to(dmo.device)
-            self._nystrom_G = G0
+            G0 = st[(key, "G0")] = torch.randn(n, nocc, generator=g, dtype=torch.float64).to(dmo.device)
+            st[(key, "G")] = G0
         # test matrix: the previous cycle's orthonormal occupied basis plus 5 % of the fixed Gaussian one.  Near convergence
-        # X G ~ G, so M ~ 2 I and the factor is accurate to rounding (a pure Gaussian G gives cond(M) ~ 1e3-1e4, i.e. 1e-12
-        # relative noise in rho -- visible as 1e-10 Ha jitter in E_xc of a 650 Ha molecule converged to conv_tol = 1e-10);
-        # the Gaussian part keeps M non-singular when the occupied space has changed completely (new geometry, new state).
-        G = self._nystrom_G
-        W = dmo @ G                                        # = 2 X G
-        M = G.T @ W                                        # = 2 G^T X G
+        # X G ~ G, so M is close to a multiple of I and the factor is accurate to rounding (a pure Gaussian G gives cond(M) ~
+        # 1e3-1e4, i.e. 1e-12 relative noise in rho -- visible as 1e-10 Ha jitter in E_xc of a 650 Ha molecule converged to
+        # conv_tol = 1e-10); the Gaussian part keeps M non-singular when the occupied space has changed completely.
+        G = st[(key, "G")]
+        W = dmo @ G
+        M = G.T @ W
         R, _info = torch.linalg.cholesky_ex(M)             # no host sync; a failed factorisation shows up as a wrong N_elec
-        Zp_t = torch.linalg.solve_triangular(R, W.T, upper=False)   # R^-1 W^T: rows orthogonal with norm^2 = 2 -> D' = Zp Zp^T
+        Zp_t = torch.linalg.solve_triangular(R, W.T, upper=False)   # R^-1 W^T: dmo = Zp Zp^T
         # (a cycle whose projector was not valid -- speculative purification, checked later by the host -- must not poison
         # the warm start: keep the Gaussian matrix unless the factor is finite and the factorisation succeeded)
         good = torch.isfinite(Zp_t).all() & (_info == 0)
-        self._nystrom_G = torch.where(good, torch.add(G0, Zp_t.T, alpha=14.142135623730951).mul_(0.05), G0)   # 0.05 G0 + Zp / sqrt(2)
+        scale = 1.0 / torch.sqrt(torch.clamp(torch.sum(Zp_t[0] * Zp_t[0]), min=1e-300))    # columns of Zp to unit norm
+        st[(key, "G")] = torch.where(good, G0 * 0.05 + Zp_t.T * scale, G0)
         return Zp_t @ self._Linv                            # (L^-T Zp)^T
 
     def _ao_cache_for(self, nao, npts, ncomp):

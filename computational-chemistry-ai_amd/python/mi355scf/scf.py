@@ -729,6 +729,7 @@ class SCF:
         n = self._Linv.shape[0]
         if not (self.pipeline and self.eig_method == "sp2" and self.sp2_planned and self._sp2_plannable(n)
                 and 0 < nocc < n and not self.level_shift and self._sp2_plan is not None
+                and st.get("gnorm", 0.0) <= self.sp2_plan_gnorm
                 and st["cycle"] + 1 >= self.diis_start_cycle and st["diis"].count > 0):
             return None
         fo = st["diis"].extrapolate()
@@ -772,9 +773,15 @@ class SCF:
             # `sp2_plan_gnorm` the trace-correcting purification runs instead -- it needs no bounds -- and the plan is made once,
             # when the SCF has settled; warm starts (dm0 from a nearby geometry) plan at their first cycle.
             early = planned_ok and self._sp2_plan is None and (st.get("gnorm", 0.0) > self.sp2_plan_gnorm or not self.sp2_plan_inloop)
-            if planned_ok and self._sp2_plan is not None and not st.get("_redo"):
+            settled = st.get("gnorm", 0.0) <= self.sp2_plan_gnorm
+            if planned_ok and self._sp2_plan is not None and settled and not st.get("_redo"):
                 dmo, tr_dev = self._sp2_planned_async(fo, nocc)
                 self._sp2_planned_pass = True
+            elif planned_ok and self._sp2_plan is not None and not settled:
+                # a plan exists (seeded by an earlier SCF of this object) but this SCF is still far from its solution -- e.g.
+                # kernel() from the atomic guess again: the spectrum is not the planned one yet (measured: three redo cycles,
+                # each a diagonalisation and a second Fock build).  Checked purification until the SCF has settled.
+                dmo = self._density_sp2(fo, nocc, orth=True)
             elif early and st.get("gnorm", 0.0) > self.sp2_plan_gnorm:
                 # checked purification (validated on the host inside, iteration count adapted there): while the spectrum still
                 # moves from cycle to cycle the optimistic variant would guess the count wrong and cost a redo cycle

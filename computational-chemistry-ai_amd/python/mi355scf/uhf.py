@@ -131,19 +131,21 @@ class UHF(SCF):
     fast_loop = True   # orthonormal-basis loop with device-side pair DIIS, planned purification per spin, pipelined step
 
     def kernel(self, dm0=None, **kw):
-        """Two loops.  The fast one (orthonormal basis, device-side pair DIIS, planned purification per spin, pipelined step)
-        needs purification plans, i.e. spectral bounds of both spins; a cold object would have to diagonalise two or three
-        times for them (7 ms each at N = 264, 40 ms at 573), which costs a short SCF more than the loop saves.  So: the first
-        SCF of an object with N >= sp2_min_nao runs the plain loop, whose final orbitals (needed for mo_energy anyway) seed the
-        plans; every later kernel() of the same object -- geometry steps, scans -- takes the fast loop.  Small molecules
-        diagonalise per cycle in either loop and always take the fast one."""
+        """Two loops.  The fast one (orthonormal basis, device-side pair DIIS, pipelined step, planned purification per spin
+        when plans exist) is the default below `sp2_min_nao` basis functions, where both loops diagonalise per cycle and it is
+        5-13 % faster (CH3/cc-pVTZ UHF 2.92 -> 2.54 ms per cycle, UKS B3LYP 2.99 -> 2.83).  Above that size it did not pay in
+        the measurements of round 2 (`tools/uhf_bench.py`, `tools/uhf_warm.py`, benzene cation / cc-pVTZ): from a cold object it
+        needs diagonalisations for its purification plans (7 ms each), and restarted from a nearby density it ran 2.15 against
+        3.1 ms per cycle but took 19 instead of 14 cycles (UKS: 8.6 against 7.2 ms per cycle), so the plain loop stays the default
+        there; `fast_loop = "always"` selects the fast loop whenever plans exist (the plain loop's final orbitals seed them)."""
         self._setup_once()
         n = self.engine.nao
         na, nb = self.mol.nelec
         self.nelec = (na, nb)
-        warm = n < self.sp2_min_nao or self.eig_method != "sp2" or all(
-            no == 0 or sp.vals["_sp2_plan"] is not None for sp, no in zip(self._spin_states(n), (na, nb)))
-        if self.fast_loop and warm and not (self._nranks > 1 and self.sync_control):
+        small = n < self.sp2_min_nao or self.eig_method != "sp2"
+        warm = all(no == 0 or sp.vals["_sp2_plan"] is not None for sp, no in zip(self._spin_states(n), (na, nb)))
+        use_fast = self.fast_loop and (small or (self.fast_loop == "always" and warm))
+        if use_fast and not (self._nranks > 1 and self.sync_control):
             return self._kernel_fast(dm0)
         return self._kernel_plain(dm0)
 
@@ -195,7 +197,13 @@ class UHF(SCF):
             return torch.zeros_like(fo), None, None, False
         can_plan = (self.eig_method == "sp2" and self.sp2_planned and n >= self.sp2_min_nao and self._sp2_plannable(n)
                     and 0 < nocc_s < n and not self.level_shift)
-        if can_plan and allow_plan and sp.vals["_sp2_plan"] is not None:
+        settled = st.get("gnorm") is not None and st["gnorm"] <= self.sp2_plan_gnorm
+        if can_plan and allow_plan and sp.vals["_sp2_plan"] is not None and not settled:
+            # plans exist but this SCF is still far from its solution (see SCF._step): checked purification, no redo cycles
+            d2 = self._density_sp2(fo, nocc_s, orth=True)
+            if d2 is not None:
+                return 0.5 * d2, None, None, False
+        if can_plan and allow_plan and sp.vals["_sp2_plan"] is not None and settled:
             x, tr = self._with_spin(sp, self._sp2_planned_async, fo, nocc_s, 1.0)
             shape, sp.vals["_sp2_hist_shape"] = sp.vals["_sp2_hist_shape"], None
             return x, tr, shape, True
@@ -212,6 +220,8 @@ class UHF(SCF):
         read-back of the scalars."""
         eng, Li = self.engine, self._Linv
         dm = dm.contiguous()
+        # from cycle 1 on the spin densities are projectors X_s of rank n_s: lets UKS take rho_s from a low-rank factor
+        self._xc_projector_pair = (dm, dmo, st["nocc"]) if next_cycle > 0 else None
         F, e_el = self._fock_pair(dm)
         diis = st["diis"]
         keep = next_cycle >= self.diis_start_cycle
@@ -281,6 +291,8 @@ class UHF(SCF):
         """Device-only head of the next cycle (pair-extrapolated F', planned purification of both spins, AO densities), queued
         before the host waits for the current cycle's scalars.  None when either spin has no plan."""
         if not (self.pipeline and st["cycle"] + 1 >= self.diis_start_cycle and st["diis"].count > 0 and not self.level_shift):
+            return None
+        if st.get("gnorm") is None or st["gnorm"] > self.sp2_plan_gnorm:
             return None
         for s_ in range(2):
             if st["nocc"][s_] > 0 and st["spin"][s_].vals["_sp2_plan"] is None:

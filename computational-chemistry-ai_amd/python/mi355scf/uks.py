@@ -42,6 +42,8 @@ class UKS(UHF):
             self._log(4, f"XC grid: {self.grids.size} points (level {self.grids.level})")
 
     _ao_cache_for = RKS._ao_cache_for
+    _lowrank_factor = RKS._lowrank_factor
+    xc_lowrank, xc_lowrank_min_nao = True, RKS.xc_lowrank_min_nao
     _grid_range = RKS._grid_range
 
     def nr_uks(self, dm):
@@ -63,6 +65,17 @@ class UKS(UHF):
         lo, hi = self._grid_range(ng)
         B = max(self.grid_block, int(1.5e9 / (64.0 * n)) // 1024 * 1024)
         cache = self._ao_cache_for(n, hi - lo, 4 if gga else 1)
+        # spin densities declared projectors by the fast UHF/UKS loop (`_xc_projector_pair`): D_s = Z_s Z_s^T without orbitals
+        Zps = [None, None]
+        proj = getattr(self, "_xc_projector_pair", None)
+        if self.xc_lowrank and proj is not None and proj[0] is dm:
+            ch = 24 if gga else 32
+            for s_ in range(2):
+                Zt = self._lowrank_factor(proj[1][s_], proj[2][s_], ("uks", s_)) if proj[2][s_] > 0 else None
+                if Zt is not None:
+                    Zp = torch.zeros(n, (Zt.shape[0] + ch - 1) // ch * ch, dtype=torch.float64, device=Zt.device)
+                    Zp[:, :Zt.shape[0]] = Zt.T
+                    Zps[s_] = Zp
         for ib, p0 in enumerate(range(lo, hi, B)):
             p1 = min(p0 + B, hi)
             c, w = coords[p0:p1], weights[p0:p1]
@@ -72,9 +85,19 @@ class UKS(UHF):
                 ao = eng.eval_ao(c, deriv=1 if gga else 0)
                 if cache is not None:
                     cache.append(ao)
-            rho = [eng.xc_rho(ao, dm[s_] @ ao[0], deriv=1 if gga else 0) for s_ in range(2)]
+            rho, tau = [None, None], [None, None]
+            for s_ in range(2):
+                if Zps[s_] is not None:      # spin density from its low-rank factor (dft.RKS._lowrank_factor), one pass over ao
+                    if gga == 2:
+                        rho[s_], tau[s_] = eng.xc_rho_lowrank(ao, Zps[s_], deriv=1, with_tau=True)
+                    else:
+                        rho[s_] = eng.xc_rho_lowrank(ao, Zps[s_], deriv=1 if gga else 0)
+                else:
+                    rho[s_] = eng.xc_rho(ao, dm[s_] @ ao[0], deriv=1 if gga else 0)
+                    if gga == 2:
+                        tau[s_] = eng.xc_tau(ao, dm[s_])
             if gga == 2:
-                e, wva, wvb = eng.xc_eval_mgga_spin(terms, rho[0], rho[1], eng.xc_tau(ao, dm[0]), eng.xc_tau(ao, dm[1]), w)
+                e, wva, wvb = eng.xc_eval_mgga_spin(terms, rho[0], rho[1], tau[0], tau[1], w)
             else:
                 e, wva, wvb = eng.xc_eval_spin(terms, rho[0], rho[1], w, gga)
             tail[0] += torch.dot(w, rho[0][0])

@@ -115,7 +115,7 @@ def test_uhf_fast_loop_with_planned_purification_equals_the_plain_loop():
     e_ref = ref.kernel()
     assert ref.converged
     mf = gpu4pyscf.scf.UHF(mol).to_gpu()
-    mf.sp2_min_nao, mf.conv_tol = 0, 1e-10
+    mf.sp2_min_nao, mf.conv_tol, mf.fast_loop = 0, 1e-10, "always"
     e_cold = mf.kernel()                               # plain loop + plans
     assert mf.converged and abs(e_cold - e_ref) < 1e-9
     assert all(sp.vals["_sp2_plan"] is not None for sp in mf._spin_pair)
@@ -127,7 +127,7 @@ def test_uhf_fast_loop_with_planned_purification_equals_the_plain_loop():
     ks_ref.xc, ks_ref.fast_loop, ks_ref.conv_tol = "B3LYP", False, 1e-10
     ek_ref = ks_ref.kernel()
     ks = gpu4pyscf.dft.UKS(mol).to_gpu()
-    ks.xc, ks.sp2_min_nao, ks.conv_tol = "B3LYP", 0, 1e-10
+    ks.xc, ks.sp2_min_nao, ks.conv_tol, ks.fast_loop = "B3LYP", 0, 1e-10, "always"
     ks.kernel()
     ek = ks.kernel(dm0=ks.make_rdm1())
     assert ks.converged and abs(ek - ek_ref) < 1e-8, (ek, ek_ref)
