@@ -164,7 +164,7 @@ class Engine:
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", device if isinstance(device, int) else device.index)
-        _warm_libraries(self.device, mol.nao, max(1, mol.nelectron // 2))
+        _warm_libraries(self.device, mol.nao, max(1, int(getattr(mol, "nelectron", 48)) // 2))
         self._atm = np.ascontiguousarray(mol._atm, dtype=np.int32)
         self._bas = np.ascontiguousarray(mol._bas, dtype=np.int32)
         self._env = np.ascontiguousarray(mol._env, dtype=np.float64)
