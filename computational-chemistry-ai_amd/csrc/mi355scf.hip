@@ -315,6 +315,11 @@ struct mi_ctx {
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
+    int opt_sp2_persist = 0; // planned purification as ONE resident launch with grid barriers (1: release/acquire fences, 2: write-through
+                             // stores + L2-bypassing loads) -- measured SLOWER than one launch per pass (0), see sp2_plan_persist_kernel
+    unsigned *d_sp2_bar = nullptr; // [0] arrival counter (monotonic), [1] abort tag
+    unsigned sp2_bar_base = 0, sp2_tag = 0;
+    int n_cu = 0;
 };
 
 static inline int pc_index(int la, int lb) { return la * (la + 1) / 2 + lb; }
@@ -466,7 +471,7 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     hipSetDevice(c->device);
     free_eri(c);
     void *ptrs[] = {c->d_env, c->d_bas, c->d_atm, c->d_shell_ao, c->d_c2s, c->d_rys_cheb, c->d_herm_r, c->d_herm_w,
-                    c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red, c->d_shell_xyz};
+                    c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red, c->d_shell_xyz, c->d_sp2_bar};
     for (void *p : ptrs) if (p) hipFree(p);
     delete c;
 }
@@ -483,6 +488,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
     else if (k == "jk_pair") c->opt_jk_pair = (int)value;
+    else if (k == "sp2_persist") c->opt_sp2_persist = (int)value;
     else if (k == "tri_tiles") c->opt_tri_tiles = (int)value;       // takes effect at the next mi_eri_prepare
     else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;
     else if (k == "tpq_maxprim") c->opt_tpq_maxprim = value;
@@ -5234,19 +5240,24 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *__restrict
 //            writes X_{k+1} = a X_k^2 + b X_k + c I   (last pass: a = c = 0, b = out_scale: the result itself),
 // so a pass loads two row panels and stores one tile where the two-matrix version loaded four and stored two.  Same triangular
 // grid, same mirror stores, same MFMA/K-split order as sp2_fused_kernel: the traces are bit-identical to that kernel's.
-template <int MAXM>
-__global__ __launch_bounds__(256) void sp2_plan_kernel(const double *__restrict__ Xin, int n, int kpad, double b_in, double c_in,
-                                                       double *__restrict__ Xout, double *__restrict__ trc, Sp2Coef nx)
+__device__ inline void sp2_tile_of_block(int b, int &bI, int &bJ)
 {
-    extern __shared__ double lds[];
+    bI = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
+    while ((bI + 1) * (bI + 2) / 2 <= b) bI++;
+    while (bI * (bI + 1) / 2 > b) bI--;
+    bJ = b - bI * (bI + 1) / 2;
+}
+// one pass for the tile (bI, bJ); no __restrict__ on the matrices: the persistent kernel below ping-pongs between two buffers
+#define SP2_LD(p) (COH ? __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *(p))
+#define SP2_ST(p, v) do { if (COH) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(p) = (v); } while (0)
+template <int MAXM, bool COH>
+__device__ __forceinline__ void sp2_plan_pass(const double *Xin, int n, int kpad, double b_in, double c_in, double *Xout, double *trc,
+                                              Sp2Coef nx, int bI, int bJ, double *lds)
+{
     double *Pa = lds;                       // [16][kpad+4]  rows i0..i0+15 of X_k
     double *Pb = lds + 16 * (kpad + 4);     // [16][kpad+4]  rows j0..j0+15 of X_k
     double *red = Pb + 16 * (kpad + 4);     // [4][256]
     const int ldp = kpad + 4;
-    int bI = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-    while ((bI + 1) * (bI + 2) / 2 <= (int)blockIdx.x) bI++;
-    while (bI * (bI + 1) / 2 > (int)blockIdx.x) bI--;
-    const int bJ = (int)blockIdx.x - bI * (bI + 1) / 2;
     const int i0 = bI * 16, j0 = bJ * 16;
     const int t = threadIdx.x, r = t >> 4, c = t & 15;
     const bool ra = i0 + r < n, rb = j0 + r < n;
@@ -5258,8 +5269,8 @@ __global__ __launch_bounds__(256) void sp2_plan_kernel(const double *__restrict_
         for (int u = 0; u < MAXM; u++) {
             const int k = c + 16 * (m0 + u);
             const bool in = (m0 + u < mtot) && k < n;
-            xa[u] = (in && ra) ? xa_row[k] : 0.0;
-            xb[u] = (in && (bI != bJ) && rb) ? xb_row[k] : 0.0;
+            xa[u] = (in && ra) ? SP2_LD(xa_row + k) : 0.0;
+            xb[u] = (in && (bI != bJ) && rb) ? SP2_LD(xb_row + k) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < MAXM; u++) {
@@ -5292,8 +5303,8 @@ __global__ __launch_bounds__(256) void sp2_plan_kernel(const double *__restrict_
             if (gi < n && gj < n) {
                 const double xc = Pa[row * ldp + gj];
                 const double dg = (gi == gj) ? nx.c : 0.0;
-                Xout[(size_t)gi * n + gj] = fma(nx.a, v, fma(nx.b, xc, dg));
-                if (bI != bJ) Xout[(size_t)gj * n + gi] = fma(nx.a, v, nx.b * Pb[col * ldp + gi]);
+                SP2_ST(Xout + (size_t)gi * n + gj, fma(nx.a, v, fma(nx.b, xc, dg)));
+                if (bI != bJ) SP2_ST(Xout + (size_t)gj * n + gi, fma(nx.a, v, nx.b * Pb[col * ldp + gi]));
                 if (gi == gj) { tr2 += v; tr1 += xc; }
             }
         }
@@ -5303,7 +5314,97 @@ __global__ __launch_bounds__(256) void sp2_plan_kernel(const double *__restrict_
         }
     }
 }
+template <int MAXM>
+__global__ __launch_bounds__(256) void sp2_plan_kernel(const double *__restrict__ Xin, int n, int kpad, double b_in, double c_in,
+                                                       double *__restrict__ Xout, double *__restrict__ trc, Sp2Coef nx)
+{
+    extern __shared__ double lds[];
+    int bI, bJ;
+    sp2_tile_of_block((int)blockIdx.x, bI, bJ);
+    sp2_plan_pass<MAXM, false>(Xin, n, kpad, b_in, c_in, Xout, trc, nx, bI, bJ, lds);
+}
+
+// The whole planned sequence in ONE launch (option sp2_persist, OFF by default): the grid of nb(nb+1)/2 <= #CU workgroups stays
+// resident and the passes are separated by a grid barrier on a counter in device memory instead of a kernel boundary.  Same
+// per-pass code (sp2_plan_pass), hence bit-identical matrices and traces (tests/test_gpu_sp2_persist.py).
+//   COH = false: agent-scope release / acquire around the counter (buffer_wbl2 sc1 before the arrival, buffer_inv sc1 after the
+//                wait: the L2 of each XCD is written back / invalidated, as at a kernel boundary);
+//   COH = true : the matrix itself moves with agent-scope accesses (global_store ... sc1 writes through, global_load ... sc1
+//                misses the XCD's L2), the counter with relaxed atomics: no cache maintenance at all.
+// MEASURED (benzene, 19 passes, profiles/r02_sp2_resident_experiment.log): cc-pVTZ one launch per pass 140-149 us, COH=false
+// 262 us, COH=true 192 us; cc-pVDZ 111 / 107 / 103 us.  A pass through the barrier costs four dependent fabric round trips
+// (load miss, store acknowledgement, arrival atomic, poll) of ~2 us each, a kernel boundary 4.6 us in total: the 21 launches per
+// cycle that VERDICT r01 item 4 wanted below 15 are the cheaper form, and the default stays one launch per pass.
+//   bar[0]: arrival counter, never reset -- the host hands in the value it must reach (`base` + passes x workgroups, modulo
+//   2^32); bar[1]: abort flag (= the launch's tag).  A workgroup that waits longer than SP2_BAR_TICKS (0.25 s of the 100 MHz clock: cannot happen
+//   while the grid is co-resident, which the host checks) raises the flag, everybody leaves, and the traces of the last pass
+//   are NaN -- the caller's validation then takes the diagonalisation path.
+#define SP2_PLAN_MAXPASS 48
+#define SP2_BAR_TICKS 25000000LL
+struct Sp2PlanArg { int nit; double coef[3 * (SP2_PLAN_MAXPASS + 1)]; };
+template <bool COH>
+__device__ inline bool sp2_grid_barrier(unsigned *bar, unsigned target, unsigned tag)
+{
+    __shared__ int ok_sh;
+    if (COH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores are acknowledged
+    __syncthreads();                          // every store of this workgroup is issued and acknowledged
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        if (COH) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        while ((int)((COH ? __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                          : __hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) { ok = 0; break; }
+            if (wall_clock64() - t0 > SP2_BAR_TICKS) { __hip_atomic_store(bar + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+        }
+        ok_sh = ok;
+    }
+    __syncthreads();
+    return ok_sh != 0;
+}
+template <int MAXM, bool COH>
+__global__ __launch_bounds__(256) void sp2_plan_persist_kernel(const double *F, int n, int kpad, double *A, double *B, double osc,
+                                                               double *tr, unsigned *bar, unsigned base, unsigned tag, Sp2PlanArg P)
+{
+    extern __shared__ double lds[];
+    int bI, bJ;
+    sp2_tile_of_block((int)blockIdx.x, bI, bJ);
+    constexpr int TS = 2 * SP2_TRS;
+    const double *in = F;
+    double *out = A, *other = B;
+    double b_in = P.coef[1], c_in = P.coef[2];
+    bool ok = true;
+    for (int k = 0; k <= P.nit; k++) {
+        const Sp2Coef nx = k < P.nit ? Sp2Coef{P.coef[3 * (k + 1)], P.coef[3 * (k + 1) + 1], P.coef[3 * (k + 1) + 2], 0.0}
+                                     : Sp2Coef{0.0, osc, 0.0, 0.0};
+        sp2_plan_pass<MAXM, COH>(in, n, kpad, b_in, c_in, out, tr + TS * k, nx, bI, bJ, lds);
+        if (k == P.nit) break;
+        ok = sp2_grid_barrier<COH>(bar, base + (unsigned)(k + 1) * gridDim.x, tag);
+        if (!ok) break;
+        in = out;
+        double *sw = out; out = other; other = sw;
+        b_in = 1.0; c_in = 0.0;
+    }
+    if (!ok && bI == bJ && threadIdx.x == 0) {
+        tr[TS * P.nit + 2 * bI] = __builtin_nan("");
+        tr[TS * P.nit + 2 * bI + 1] = __builtin_nan("");
+    }
+}
 typedef void (*sp2_plan_fn)(const double *, int, int, double, double, double *, double *, Sp2Coef);
+typedef void (*sp2_persist_fn)(const double *, int, int, double *, double *, double, double *, unsigned *, unsigned, unsigned, Sp2PlanArg);
+template <bool COH> static sp2_persist_fn sp2_persist_for_t(int kpad)
+{
+    const int m = kpad >> 4;
+    if (m <= 8) return sp2_plan_persist_kernel<8, COH>;
+    if (m <= 12) return sp2_plan_persist_kernel<12, COH>;
+    if (m <= 16) return sp2_plan_persist_kernel<16, COH>;
+    if (m <= 20) return sp2_plan_persist_kernel<20, COH>;
+    return sp2_plan_persist_kernel<16, COH>; // two batches
+}
+static sp2_persist_fn sp2_persist_for(int kpad, bool coh) { return coh ? sp2_persist_for_t<true>(kpad) : sp2_persist_for_t<false>(kpad); }
+
 static sp2_plan_fn sp2_plan_for(int kpad)
 {
     const int m = kpad >> 4;
@@ -5418,6 +5519,32 @@ extern "C" int mi_sp2_iterate_planned(mi_ctx *c, const double *d_F, double *d_A,
         return k < nit ? Sp2Coef{coef[3 * (k + 1)], coef[3 * (k + 1) + 1], coef[3 * (k + 1) + 2], 0.0} : Sp2Coef{0.0, osc, 0.0, 0.0};
     };
     double *cur = d_A, *nxt = d_B;
+    if (c->opt_sp2_persist && nit >= 1 && nit <= SP2_PLAN_MAXPASS) {
+        if (!c->n_cu) {
+            HIPCHK(hipSetDevice(c->device));
+            HIPCHK(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+        }
+        // co-residency: one workgroup per CU (79 KB of LDS each), so the grid must not exceed the CU count
+        if ((int)grid.x <= c->n_cu) {
+            if (!c->d_sp2_bar) {
+                HIPCHK(hipMalloc(&c->d_sp2_bar, 2 * sizeof(unsigned)));
+                HIPCHK(hipMemsetAsync(c->d_sp2_bar, 0, 2 * sizeof(unsigned), st));
+                c->sp2_bar_base = 0; c->sp2_tag = 0;
+            }
+            Sp2PlanArg P;
+            P.nit = nit;
+            for (int i = 0; i < 3 * (nit + 1); i++) P.coef[i] = coef[i];
+            c->sp2_tag++;
+            if (c->sp2_tag == 0) c->sp2_tag = 1;
+            hipLaunchKernelGGL(sp2_persist_for(kpad, c->opt_sp2_persist == 2), grid, block, shm, st, d_F, n, kpad, d_A, d_B, osc, d_tr, c->d_sp2_bar, c->sp2_bar_base,
+                               c->sp2_tag, P);
+            HIPCHK(hipGetLastError());
+            c->sp2_bar_base += (unsigned)nit * grid.x;
+            *d_tr_out = d_tr + TS * nit;
+            *d_res = (nit % 2 == 0) ? d_A : d_B;   // pass k writes A for even k, B for odd k
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(kern, grid, block, shm, st, d_F, n, kpad, coef[1], coef[2], cur, d_tr, next_coef(0));
     for (int it = 1; it <= nit; it++) {
         hipLaunchKernelGGL(kern, grid, block, shm, st, cur, n, kpad, 1.0, 0.0, nxt, d_tr + TS * it, next_coef(it));
