@@ -5129,6 +5129,10 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
 //   (no atomics: bit-identical on every rank of a sharded run).
 // =================================================================================================
 #define SP2_TRS 32 /* trace slots per step = max diagonal workgroups (N <= 512) */
+// LDS row padding of the panels (doubles).  The MFMA operand read is "16 rows x 4 consecutive k" per wave; a row stride of
+// 2 (mod 32) doubles = 4 banks (mod 64) puts the 32 lanes of a half wave on 64 distinct banks, the former +4 made rows r and
+// r + 8 collide (two-way conflict on every operand read).
+#define SP2_PAD 2
 // MAXM = 16-column groups a thread loads per panel row in one batch: all 4 x MAXM loads of a thread are in flight together
 // (one memory round trip for kpad <= 16 MAXM; larger matrices take two batches).  Thread t owns row t/16 and columns
 // t%16 + 16 m of both panels: no integer division, 128-byte segments per row and instruction.
@@ -5142,10 +5146,10 @@ __global__ __launch_bounds__(256) void sp2_fused_kernel(const double *__restrict
                                                         Sp2Coef cf)
 {
     extern __shared__ double lds[];
-    double *Pa = lds;                       // [16][kpad+4]  rows i0..i0+15 of Xc
-    double *Pb = lds + 16 * (kpad + 4);     // [16][kpad+4]  rows j0..j0+15 of Xc
-    double *red = Pb + 16 * (kpad + 4);     // [4][256]  (its first 64 doubles also stage the partial traces)
-    const int ldp = kpad + 4;               // +4 doubles: breaks the power-of-two LDS row stride
+    double *Pa = lds;                       // [16][kpad+SP2_PAD]  rows i0..i0+15 of Xc
+    double *Pb = lds + 16 * (kpad + SP2_PAD);     // [16][kpad+SP2_PAD]  rows j0..j0+15 of Xc
+    double *red = Pb + 16 * (kpad + SP2_PAD);     // [4][256]  (its first 64 doubles also stage the partial traces)
+    const int ldp = kpad + SP2_PAD;
     // X and X^2 are symmetric: only the tiles (I >= J) are computed (grid = nb(nb+1)/2 workgroups -- 153 for N = 264, one round
     // on 256 CUs instead of 289 in two) and every off-diagonal tile is stored with its mirror image.  The mirrored values are
     // bit-identical to what the (J, I) workgroup used to compute (same products, same k order).
@@ -5254,10 +5258,10 @@ template <int MAXM, bool COH>
 __device__ __forceinline__ void sp2_plan_pass(const double *Xin, int n, int kpad, double b_in, double c_in, double *Xout, double *trc,
                                               Sp2Coef nx, int bI, int bJ, double *lds)
 {
-    double *Pa = lds;                       // [16][kpad+4]  rows i0..i0+15 of X_k
-    double *Pb = lds + 16 * (kpad + 4);     // [16][kpad+4]  rows j0..j0+15 of X_k
-    double *red = Pb + 16 * (kpad + 4);     // [4][256]
-    const int ldp = kpad + 4;
+    double *Pa = lds;                       // [16][kpad+SP2_PAD]  rows i0..i0+15 of X_k
+    double *Pb = lds + 16 * (kpad + SP2_PAD);     // [16][kpad+SP2_PAD]  rows j0..j0+15 of X_k
+    double *red = Pb + 16 * (kpad + SP2_PAD);     // [4][256]
+    const int ldp = kpad + SP2_PAD;
     const int i0 = bI * 16, j0 = bJ * 16;
     const int t = threadIdx.x, r = t >> 4, c = t & 15;
     const bool ra = i0 + r < n, rb = j0 + r < n;
@@ -5438,7 +5442,7 @@ extern "C" int mi_sp2_iterate(mi_ctx *c, double *d_X, double *d_X2, int nit, dou
     if (n > 512) return fail("mi_sp2_iterate: fused path is for N <= 512");
     hipStream_t st = (hipStream_t)stream;
     const int kpad = ((n + 15) / 16) * 16;
-    const size_t shm = sizeof(double) * (2 * 16 * (kpad + 4) + 4 * 256);
+    const size_t shm = sizeof(double) * (2 * 16 * (kpad + SP2_PAD) + 4 * 256);
     const int nb = (n + 15) / 16;
     dim3 grid(nb * (nb + 1) / 2), block(256);
     const size_t nn = (size_t)n * n;
@@ -5474,7 +5478,7 @@ extern "C" int mi_sp2_iterate_pingpong(mi_ctx *c, double *d_A, double *d_B, int 
     if (n > 512) return fail("mi_sp2_iterate_pingpong: fused path is for N <= 512");
     hipStream_t st = (hipStream_t)stream;
     const int kpad = ((n + 15) / 16) * 16;
-    const size_t shm = sizeof(double) * (2 * 16 * (kpad + 4) + 4 * 256);
+    const size_t shm = sizeof(double) * (2 * 16 * (kpad + SP2_PAD) + 4 * 256);
     const int nb = (n + 15) / 16;
     dim3 grid(nb * (nb + 1) / 2), block(256);
     const size_t nn = (size_t)n * n;
@@ -5508,7 +5512,7 @@ extern "C" int mi_sp2_iterate_planned(mi_ctx *c, const double *d_F, double *d_A,
     if (n > 512) return fail("mi_sp2_iterate_planned: fused path is for N <= 512");
     hipStream_t st = (hipStream_t)stream;
     const int kpad = ((n + 15) / 16) * 16;
-    const size_t shm = sizeof(double) * (2 * 16 * (kpad + 4) + 4 * 256);
+    const size_t shm = sizeof(double) * (2 * 16 * (kpad + SP2_PAD) + 4 * 256);
     const int nb = (n + 15) / 16;
     dim3 grid(nb * (nb + 1) / 2), block(256);
     const size_t nn = (size_t)n * n;
@@ -5630,10 +5634,11 @@ extern "C" int mi_commutator_norm(mi_ctx *c, const double *d_M, double *d_E, dou
 // =================================================================================================
 #define VM_T 64
 #define VM_KS 64
+#define VM_PAD 2 /* see SP2_PAD: conflict-free operand reads for 16 rows x 4 k */
 __global__ __launch_bounds__(256) void xc_vmat_kernel(const double *__restrict__ A, const double *__restrict__ W, int nao, int64_t ng,
                                                       int64_t kchunk, double *C)
 {
-    __shared__ double Pa[VM_T][VM_KS + 4], Pb[VM_T][VM_KS + 4];
+    __shared__ double Pa[VM_T][VM_KS + VM_PAD], Pb[VM_T][VM_KS + VM_PAD];
     const int m0 = blockIdx.y * VM_T, n0 = blockIdx.x * VM_T;
     const int64_t kbeg = (int64_t)blockIdx.z * kchunk, kend = min(ng, kbeg + kchunk);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -164,7 +164,7 @@ def optimize_internal(energy_grad, mol, maxsteps=100, log=lambda m: None, callba
     Ginv, P, rank = ic.ginv(B)
     if n < 2 or ic.has_linear or rank < max(3 * n - 6, 1):
         return None
-    H = np.diag(ic.guess_hessian_diag())
+    H = np.diag(ic.guess_hessian_diag(x))
     trust = 0.3
     e, g = energy_grad(mol)
     gq = Ginv @ (B @ g.ravel())

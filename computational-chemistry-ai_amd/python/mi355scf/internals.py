@@ -7,6 +7,7 @@ back-transformation of an internal-coordinate step to Cartesians [Peng, Ayala, S
 (1996); Bakken, Helgaker, JCP 117, 9160 (2002)].
 """
 import itertools
+import os
 
 import numpy as np
 
@@ -63,6 +64,7 @@ class Internals:
     def __init__(self, z, x):
         n = len(x)
         self.natm = n
+        self.z = np.asarray(z, dtype=int)
         bonds = bond_graph(z, x)
         nb = [[] for _ in range(n)]
         for i, j in bonds:
@@ -71,6 +73,7 @@ class Internals:
         for b in bonds:
             self.kinds.append("bond"); self.atoms.append(b)
         self.has_linear = False
+        self.oop = set()            # indices of the out-of-plane torsions (their middle pair is not bonded)
         for j in range(n):
             for i, k in itertools.combinations(sorted(nb[j]), 2):
                 if _angle_value(x, i, j, k) > LINEAR:
@@ -94,6 +97,7 @@ class Internals:
                 if min(_angle_value(x, c, a, b), _angle_value(x, a, b, d_)) > np.deg2rad(5.0) and \
                         max(_angle_value(x, c, a, b), _angle_value(x, a, b, d_)) < LINEAR:
                     self.kinds.append("dihedral"); self.atoms.append((c, a, b, d_))
+                    self.oop.add(len(self.kinds) - 1)
         self.nq = len(self.kinds)
 
     # ---------------------------------------------------------------------------------------------
@@ -151,9 +155,40 @@ class Internals:
                 row[i] += di; row[j] += dj; row[k] += dk; row[l] += dl
         return B
 
-    def guess_hessian_diag(self):
-        """Schlegel-type diagonal guess (a.u.): stretches 0.5, bends 0.2, torsions 0.1 (0.045 for out-of-plane)."""
-        return np.array([{"bond": 0.5, "angle": 0.2, "dihedral": 0.1}[k] for k in self.kinds])
+    HESS_MODEL = "lindh"
+
+    def guess_hessian_diag(self, x=None, model=None):
+        """Diagonal guess (a.u.) for the primitives.
+        "lindh" (default): Lindh, Bernhardsson, Karlstrom, Malmqvist, CPL 241, 423 (1995) -- k = 0.45 rho_ij (stretch),
+            0.15 rho_ij rho_jk (bend), 0.005 rho_ij rho_jk rho_kl (torsion), rho_ij = exp(alpha_ij (r_ref,ij^2 - r_ij^2)) with
+            alpha / r_ref tabulated per pair of periods: soft torsions, so that the many redundant torsions about one rotatable
+            bond do not add up to a rotor forty times stiffer than it is (the round-1 constants did, and the optimisation of
+            ibuprofen crawled along its methyl / isobutyl rotors for ten steps);
+        "geometric": the constants geomeTRIC [MEM] starts from (0.35 / 0.16 / 0.023);
+        "simple": round 1 (0.5 / 0.2 / 0.1)."""
+        model = (model or os.environ.get("MI355_OPT_HESS") or self.HESS_MODEL).lower()
+        if model == "simple":
+            return np.array([{"bond": 0.5, "angle": 0.2, "dihedral": 0.1}[k] for k in self.kinds])
+        if model == "geometric" or x is None:
+            return np.array([{"bond": 0.35, "angle": 0.16, "dihedral": 0.023}[k] for k in self.kinds])
+        per = np.where(self.z <= 2, 0, np.where(self.z <= 10, 1, 2))
+        alpha = np.array([[1.0000, 0.3949, 0.3949], [0.3949, 0.2800, 0.2800], [0.3949, 0.2800, 0.2800]])
+        rref = np.array([[1.35, 2.10, 2.53], [2.10, 2.87, 3.40], [2.53, 3.40, 3.40]])
+
+        def rho(i, j):
+            r2 = float(((x[i] - x[j]) ** 2).sum())
+            return np.exp(alpha[per[i], per[j]] * (rref[per[i], per[j]] ** 2 - r2))
+        out = []
+        for q, (k, a) in enumerate(zip(self.kinds, self.atoms)):
+            if q in self.oop:     # centre c = a[0] with neighbours a[1:]: geomeTRIC's out-of-plane constant, Lindh-damped bonds
+                out.append(0.045 * rho(a[0], a[1]) * rho(a[0], a[2]) * rho(a[0], a[3]))
+            elif k == "bond":
+                out.append(0.45 * rho(a[0], a[1]))
+            elif k == "angle":
+                out.append(0.15 * rho(a[0], a[1]) * rho(a[1], a[2]))
+            else:
+                out.append(0.005 * rho(a[0], a[1]) * rho(a[1], a[2]) * rho(a[2], a[3]))
+        return np.maximum(np.array(out), 1e-3)
 
     @staticmethod
     def ginv(B):
