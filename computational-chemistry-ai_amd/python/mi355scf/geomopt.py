@@ -6,7 +6,7 @@ independent quasi-Newton optimiser with geomeTRIC's DEFAULT convergence set [MEM
 RMS/max gradient < 3e-4 / 4.5e-4 Ha/Bohr, RMS/max displacement < 1.2e-3 / 1.8e-3 Angstrom.  Step-for-step
 parity with geomeTRIC is impossible; only the converged geometry/energy within those thresholds is comparable.
 Default: BFGS in redundant primitive internal coordinates (`internals.py`: stretches, bends, torsions on the
-detected bond graph; diagonal 0.5/0.2/0.1 a.u. Hessian guess; trust-radius restricted steps; iterative
+detected bond graph; Lindh model-Hessian guess (diagonal, `Internals.guess_hessian_diag`); trust-radius restricted steps; iterative
 back-transformation).  Fallback (linear bends, rank-deficient primitive sets): BFGS in Cartesian coordinates
 on the valence-force-field model Hessian B^T K B.  Returns a `Mole` at the optimised geometry, like the PySCF
 wrapper.
