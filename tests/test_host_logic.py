@@ -198,6 +198,61 @@ def test_optimizers_reach_the_same_minimum_on_a_model_surface():
     assert geomopt.optimize_internal(energy_grad, co2, 5) is None
 
 
+def test_initial_hessian_models_of_the_optimiser():
+    """`Internals.guess_hessian_diag`: Lindh's model (CPL 241, 423 (1995)) at known distances, the out-of-plane primitives of
+    three-coordinate centres, and -- on a model surface with soft rotors (torsion constants of 0.005 a.u.) -- no more steps
+    than the stiff round-1 constants need (on ibuprofen B3LYP/def2-TZVP: 12 instead of 22)."""
+    from mi355scf import geomopt
+    from mi355scf.internals import Internals
+    mol = _fixture_mol("CC(=O)O")
+    x = mol.atom_coords()
+    ic = Internals(mol.atom_charges(), x)
+    kinds = np.array(ic.kinds)
+    lin, simple, geo = (ic.guess_hessian_diag(x, m) for m in ("lindh", "simple", "geometric"))
+    assert set(np.unique(simple)) == {0.5, 0.2, 0.1} and set(np.unique(geo)) == {0.35, 0.16, 0.023}
+    z = mol.atom_charges()
+    per = lambda q: 0 if q <= 2 else 1
+    alpha = {(0, 0): 1.0, (0, 1): 0.3949, (1, 0): 0.3949, (1, 1): 0.28}
+    rref = {(0, 0): 1.35, (0, 1): 2.10, (1, 0): 2.10, (1, 1): 2.87}
+    for q, (k, a) in enumerate(zip(ic.kinds, ic.atoms)):
+        if k == "bond":
+            i, j = a
+            key = (per(z[i]), per(z[j]))
+            r2 = float(((x[i] - x[j]) ** 2).sum())
+            assert abs(lin[q] - 0.45 * np.exp(alpha[key] * (rref[key] ** 2 - r2))) < 1e-12
+    assert len(ic.oop) == 1                                            # the carboxyl carbon
+    tors = [q for q in range(ic.nq) if kinds[q] == "dihedral" and q not in ic.oop]
+    assert lin[tors].max() < 0.03 and lin[tors].min() >= 1e-3           # soft torsions
+    assert all(0.02 < lin[q] < 0.2 for q in ic.oop)                     # out-of-plane: 0.045 x bond factors, not a torsion value
+    assert 0.3 < lin[kinds == "bond"].min() and lin[kinds == "bond"].max() < 1.3 and 0.1 < lin[kinds == "angle"].min()
+
+    big = _fixture_mol("CCO")
+    icb = Internals(big.atom_charges(), big.atom_coords())
+    rng = np.random.default_rng(5)
+    q0 = icb.values(big.atom_coords())
+    kb = np.array(icb.kinds)
+    kf = np.where(kb == "bond", 0.55, np.where(kb == "angle", 0.2, 0.005))
+    q0 = q0 + np.where(kb == "dihedral", rng.normal(scale=0.25, size=icb.nq), rng.normal(scale=0.04, size=icb.nq))
+
+    def energy_grad(m):
+        xx = m.atom_coords()
+        B = icb.bmatrix(xx)
+        d = icb.diff(icb.values(xx), q0)
+        return 0.5 * float(np.sum(kf * d * d)), (B.T @ (kf * d)).reshape(-1, 3)
+
+    steps = {}
+    old = Internals.HESS_MODEL
+    try:
+        for model in ("simple", "lindh"):
+            Internals.HESS_MODEL = model
+            m, ok, n = geomopt.optimize_internal(energy_grad, big, 100)
+            assert ok
+            steps[model] = n
+    finally:
+        Internals.HESS_MODEL = old
+    assert steps["lindh"] <= steps["simple"], steps
+
+
 def test_thermo_symmetry_numbers_and_diatomic_model():
     """`pyscf.hessian.thermo` host logic: rotational symmetry numbers by brute-force rotation search, harmonic analysis of
     a model diatomic Hessian (omega = sqrt(k/mu)), RRHO identities."""
