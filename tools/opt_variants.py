@@ -25,12 +25,16 @@ for smi, basis in cases:
         mol = gto.Mole(); mol.atom = atoms(smi); mol.basis = basis; mol.verbose = 0; mol.build()
         mf = dft.RKS(mol); mf.xc = "B3LYP"; mf = mf.to_gpu()
         mf.kernel()
+        cyc, orig = [0], mf.kernel
+        def counted(*a, **kw):
+            r = orig(*a, **kw); cyc[0] += mf.cycles; return r
+        mf.kernel = counted
         steps = []
         t0 = time.time()
         mol_eq = optimize(mf, maxsteps=100, callback=lambda loc: steps.append((loc["step"], float(loc["e_new"]))))
         torch.cuda.synchronize()
         print(json.dumps(dict(molecule=smi, basis=basis, model=model, energy_evals=len(steps), last_step=steps[-1][0],
-                              e_final=steps[-1][1], wall_s=round(time.time() - t0, 1),
+                              e_final=steps[-1][1], scf_cycles=cyc[0], wall_s=round(time.time() - t0, 1),
                               trace=[round(e - steps[-1][1], 8) for _, e in steps])), flush=True)
         mf._eng = None
         del mf
