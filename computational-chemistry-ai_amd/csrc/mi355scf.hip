@@ -5130,8 +5130,9 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
 // =================================================================================================
 #define SP2_TRS 32 /* trace slots per step = max diagonal workgroups (N <= 512) */
 // LDS row padding of the panels (doubles).  The MFMA operand read is "16 rows x 4 consecutive k" per wave; a row stride of
-// 2 (mod 32) doubles = 4 banks (mod 64) puts the 32 lanes of a half wave on 64 distinct banks, the former +4 made rows r and
-// r + 8 collide (two-way conflict on every operand read).
+// 2 (mod 32) doubles = 4 banks (mod 64) puts the 32 lanes of a half wave on 64 distinct banks, where +4 makes rows r and r + 8
+// share banks.  Measured (round 2): no difference in kernel time for either padding, here (7.3-7.4 us per pass) or in xc_vmat
+// (518 vs 543 us on boxes whose J/K pass differed by more) -- the operand reads are not what bounds these kernels.
 #define SP2_PAD 2
 // MAXM = 16-column groups a thread loads per panel row in one batch: all 4 x MAXM loads of a thread are in flight together
 // (one memory round trip for kpad <= 16 MAXM; larger matrices take two batches).  Thread t owns row t/16 and columns
