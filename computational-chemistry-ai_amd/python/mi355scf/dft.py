@@ -52,6 +52,7 @@ class RKS(RHF):
     xc = "LDA,VWN"
     grid_block = 32768
     cache_ao = True
+    direct_reserve_gb = 10.0  # direct mode: room kept for the quadrature (AO blocks, optional AO cache) beside the tile groups
     small_rho_cutoff = 1e-7   # PySCF RKS default [MEM]
 
     def __init__(self, mol, xc=None):

@@ -168,6 +168,8 @@ class SCF:
         self._dm = None
         self._rank, self._nranks, self._pg = 0, 1, None
         self._stream_groups = 1   # >1: direct mode (ERI tile groups recomputed each Fock build)
+        self._resident_groups = 0  # direct mode: leading groups kept in HBM on engines of their own
+        self._group_engines = []
         self.timing = {}
         self._auto_shard()
 
@@ -220,7 +222,13 @@ class SCF:
             self.mol = mol
         self._eng = None
         self._h1 = None
+        self._drop_group_engines()
         return self
+
+    def _drop_group_engines(self):
+        for g in getattr(self, "_group_engines", []):
+            g.close()
+        self._group_engines = []
 
     # --- pieces of the Fock build ---------------------------------------------------------------
     def _setup(self):
@@ -258,8 +266,11 @@ class SCF:
             except _engine.EngineOutOfMemory as e:   # MI_ERR_NOMEM: sizes come through the ABI (mi_eri_get_memory)
                 need, free = e.need_bytes * 1e-9, e.free_bytes * 1e-9
                 self._stream_groups = int(np.ceil(need / max(0.8 * free, 1.0)))
+                if self.direct_resident:
+                    self._stream_groups, self._resident_groups = self._plan_direct_groups(need, free, self._stream_groups)
                 self._log(3, f"ERI tensor shard ({need:.0f} GB) exceeds free HBM ({free:.0f} GB): direct mode, "
-                             f"{self._stream_groups} tile groups are re-evaluated and digested every Fock build")
+                             f"{self._stream_groups} tile groups, {self._resident_groups} kept resident, the others "
+                             "re-evaluated and digested every Fock build")
         self.timing["setup_seconds"] = time.time() - t0
 
     def get_ovlp(self, mol=None):
@@ -272,17 +283,64 @@ class SCF:
     def energy_nuc(self):
         return self.mol.energy_nuc()
 
+    direct_resident = True     # direct mode: keep leading tile groups resident (engines of their own) when that pays
+    direct_reserve_gb = 2.0    # ... leaving this much (beyond 15 % of the HBM) beside the streaming buffer; Kohn-Sham classes: 10
+
+    def _plan_direct_groups(self, need_gb, free_gb, ng_min):
+        """(number of tile groups, how many of them stay resident) for a tensor of `need_gb` that does not fit `free_gb`.
+        Evaluating ONE group costs a fixed part (host planning of the whole tensor 0.17 s + every quartet of the molecule is
+        enumerated and the ones of other groups skipped 0.3 s, C60/6-31G*: tools/prepare_laps.py) plus its share of the 1.65 s
+        the quartets themselves take, so a Fock build with s streamed groups out of ng costs about s (0.28 + 1 / ng) in units
+        of the latter: many small groups pack the HBM better but pay the fixed part too often (measured: 16 groups with 7
+        resident 5.3 s per build, 3 groups with none 3.4 s).  C60 on one 288 GB GPU: 4 groups, 1 resident (-14 %)."""
+        usable = 0.85 * free_gb - self.direct_reserve_gb
+        best = (ng_min * (0.28 + 1.0 / ng_min), ng_min, 0)
+        for ng in range(ng_min, ng_min + 6):
+            g = 1.02 * need_gb / ng
+            if g > usable:
+                continue
+            r = min(int((usable - g) // g), ng - 1)
+            cost = (ng - r) * (0.28 + 1.0 / ng)
+            if cost < best[0] - 1e-9:
+                best = (cost, ng, r)
+        return best[1], best[2]
+
     def _jk_streamed(self, dm, with_j, with_k):
-        """Direct (recompute) mode: the rank's tile runs are cut into `_stream_groups` groups; each group is
-        evaluated by the Rys kernels, digested and discarded (same kernels as the resident mode)."""
+        """Direct (recompute) mode: the rank's tile runs are cut into `_stream_groups` groups (LPT dealing by bytes inside
+        `mi_eri_prepare(rank * ng + v, nranks * ng)`, so the groups are equal shares).  The first `_resident_groups` of them
+        are evaluated ONCE per geometry on engines of their own and stay in HBM (as many as fit beside one streaming buffer);
+        the others are evaluated by the Rys kernels, digested and discarded every Fock build.  Same kernels as the resident
+        mode; C60/6-31G* (499 GB of tiles) on one 288 GB GPU keeps 7 of 16 groups, so a Fock build re-evaluates 56 % of the
+        tensor instead of all of it."""
         eng = self.engine
         ng = self._stream_groups
         J = K = None
-        for v in range(ng):
-            eng.prepare_eri(self.direct_scf_tol, self._rank * ng + v, self._nranks * ng)
-            j, k = eng.get_jk(dm, with_j, with_k)
+
+        def add(j, k):
+            nonlocal J, K
             J = j if J is None else (J + j if with_j else None)
             K = k if K is None else (K + k if with_k else None)
+
+        ge = self._group_engines
+        nres = min(int(getattr(self, "_resident_groups", 0) or 0), ng - 1)
+        while len(ge) < nres:
+            v = len(ge)
+            g = _engine.Engine(self.mol, device=eng.device)
+            try:
+                g.prepare_eri(self.direct_scf_tol, self._rank * ng + v, self._nranks * ng)
+            except _engine.EngineOutOfMemory:
+                g.close()
+                nres = self._resident_groups = len(ge)
+                break
+            ge.append(g)
+            free, _tot = torch.cuda.mem_get_info(eng.device)
+            if free < 2.3 * g.stats()["stored_bytes"] + self.direct_reserve_gb * 2 ** 30:
+                nres = self._resident_groups = len(ge)   # no room for one more AND the streaming buffer of the other groups
+        for g in ge[:nres]:
+            add(*g.get_jk(dm, with_j, with_k))
+        for v in range(nres, ng):
+            eng.prepare_eri(self.direct_scf_tol, self._rank * ng + v, self._nranks * ng)
+            add(*eng.get_jk(dm, with_j, with_k))
         return J, K   # pair records / Schwarz data of the last group stay valid (used by the gradient)
 
     def _jk(self, dm, with_j=True, with_k=True):

@@ -18,6 +18,7 @@ class UKS(UHF):
     xc = "LDA,VWN"
     grid_block = RKS.grid_block
     cache_ao = True
+    direct_reserve_gb = RKS.direct_reserve_gb
 
     def __init__(self, mol, xc=None):
         UHF.__init__(self, mol)

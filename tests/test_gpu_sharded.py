@@ -111,6 +111,36 @@ def test_direct_mode_streamed_tile_groups_match_resident():
     assert mf.converged and abs(e1 - e3) < 1e-9
 
 
+def test_direct_mode_with_resident_tile_groups_matches_resident():
+    """Partially resident direct mode: the first groups are evaluated once on engines of their own and kept in HBM, the
+    others are re-evaluated every Fock build (C60/6-31G* on one GPU: 7 of 16 groups stay).  Energy and gradient equal the
+    fully resident mode; a geometry change drops the group engines."""
+    import numpy as np
+    from pyscf import gto, scf, dft
+    mol = gto.Mole()
+    mol.atom = MOLECULES["h2co"]
+    mol.basis = "6-31G(d)"
+    mol.verbose = 0
+    mol.build()
+    for make in (lambda: scf.RHF(mol), lambda: dft.RKS(mol, xc="B3LYP")):
+        ref = make()
+        ref.conv_tol = 1e-11
+        e1 = ref.kernel()
+        g1 = ref.nuc_grad_method().kernel()
+        mf = make()
+        mf.conv_tol = 1e-11
+        mf._stream_groups, mf._resident_groups = 5, 3
+        e5 = mf.kernel()
+        assert mf.converged and abs(e1 - e5) < 1e-9
+        assert len(mf._group_engines) == 3 and all(g.eri_ready for g in mf._group_engines)
+        g5 = mf.nuc_grad_method().kernel()
+        assert np.abs(g5 - g1).max() < 1e-8
+        mf._resident_groups = 9                      # more than ng - 1: one group always streams through the main engine
+        mf.reset(mol)
+        assert mf._group_engines == []
+        assert abs(mf.kernel() - e1) < 1e-9 and len(mf._group_engines) == 4
+
+
 def test_direct_mode_gradient_matches_resident():
     """in direct mode the last `mi_eri_prepare` split is a tile GROUP (rank*ng + v of nranks*ng); the
     derivative-quartet batches must still be shared by (rank, nranks) only -- `mi_grad_eri_sharded` takes them explicitly.
