@@ -45,10 +45,21 @@ int mi_ctx_nao(const mi_ctx *ctx);
  * device (geometry optimisation); this frees the parked stores. */
 void mi_release_cache(void);
 
-/* Tunables (project-defined, no reference counterpart), effective at the next mi_eri_prepare:
- * "runmax" tiles per J/K work item (0 = auto), "jk_waves" 0 = one wave per work item, longest first;
- * N > 0 = N waves with equal-cost contiguous shares;
- * immediate: "jk_nt" 1 = nontemporal loads for the tile stream. */
+/* Tunables (project-defined, no reference counterpart).  Unknown keys are an error.
+ * Effective at the next mi_eri_prepare:
+ *   "runmax"      tiles per J/K work item (0 = auto)
+ *   "jk_waves"    0 = one wave per work item, longest first; N > 0 = N waves with equal-cost contiguous shares
+ *   "tri_tiles"   1 = block-diagonal tiles store triangular rows (default), 0 = full rows
+ *   "xf_mfma_min" transform kernel: FP64-MFMA tiles for spherical blocks of at least this many elements
+ *   "eri_tpq", "tpq_maxprim"  thread-per-quartet kernels for the low angular classes / their contraction-depth limit
+ * Immediate:
+ *   "jk_nt"       nontemporal loads for the tile stream (1 = when the tensor exceeds the Infinity Cache, 2 = always, 0 = never)
+ *   "jk_cache_mb" MiB of tiles read with the default cache policy on such tensors (default 160)
+ *   "jk_pipe"     half-tile software pipeline for full-row tiles (-1 auto)
+ *   "jk_pair"     n_dm = 2: one pass with two waves per work item (-1 = for stores > 16 GB, 0 = one pass per density, 1 = always)
+ *   "grad_dtol"   derivative quartets with q_ab q_cd max|G| below this are skipped (default 1e-13, 0 = Schwarz only)
+ *   "sp2_persist" planned purification as ONE resident launch with grid barriers (0 = one launch per pass, default and faster;
+ *                 1 = release/acquire fences, 2 = write-through stores + L2-bypassing loads) */
 int mi_set_option(mi_ctx *ctx, const char *key, double value);
 
 /* One-electron integrals into device buffers (any of them may be NULL): overlap S, kinetic T, nuclear
