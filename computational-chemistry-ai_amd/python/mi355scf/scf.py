@@ -310,8 +310,8 @@ class SCF:
         `mi_eri_prepare(rank * ng + v, nranks * ng)`, so the groups are equal shares).  The first `_resident_groups` of them
         are evaluated ONCE per geometry on engines of their own and stay in HBM (as many as fit beside one streaming buffer);
         the others are evaluated by the Rys kernels, digested and discarded every Fock build.  Same kernels as the resident
-        mode; C60/6-31G* (499 GB of tiles) on one 288 GB GPU keeps 7 of 16 groups, so a Fock build re-evaluates 56 % of the
-        tensor instead of all of it."""
+        mode; (groups, resident) come from `_plan_direct_groups`: C60/6-31G* (499 GB of tiles) on one 288 GB GPU keeps 1 of 4
+        groups, so a Fock build re-evaluates 75 % of the tensor in three passes instead of all of it in three."""
         eng = self.engine
         ng = self._stream_groups
         J = K = None
