@@ -315,6 +315,7 @@ struct mi_ctx {
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
+    int opt_vmat_wgs = 0;    // xc_vmat: workgroups aimed at by the split over the grid points (0: 1024 = two per CU; -1: round-1 formula)
     int opt_sp2_persist = 0; // planned purification as ONE resident launch with grid barriers (1: release/acquire fences, 2: write-through
                              // stores + L2-bypassing loads) -- measured SLOWER than one launch per pass (0), see sp2_plan_persist_kernel
     unsigned *d_sp2_bar = nullptr; // [0] arrival counter (monotonic), [1] abort tag
@@ -489,6 +490,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
     else if (k == "jk_pair") c->opt_jk_pair = (int)value;
     else if (k == "sp2_persist") c->opt_sp2_persist = (int)value;
+    else if (k == "vmat_wgs") c->opt_vmat_wgs = (int)value;
     else if (k == "tri_tiles") c->opt_tri_tiles = (int)value;       // takes effect at the next mi_eri_prepare
     else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;
     else if (k == "tpq_maxprim") c->opt_tpq_maxprim = value;
@@ -5719,7 +5721,15 @@ extern "C" int mi_xc_vmat(mi_ctx *c, const double *d_ao0, const double *d_aow, i
 {
     if (!c || !d_ao0 || !d_aow || !d_vmat) return fail("mi_xc_vmat: null argument");
     const int nt = (c->nao + VM_T - 1) / VM_T;
-    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>((ng + 511) / 512, (1024 + nt * nt - 1) / (nt * nt)));
+    // Split over the grid points: nt^2 x nsplit workgroups, two of which fit a CU (68 KB of LDS each), i.e. 512 run at a time.
+    // Round 1 rounded nsplit UP to reach 1024 -- 1025 workgroups for benzene/cc-pVTZ, 1053 for ibuprofen/def2-TZVP: a third,
+    // almost empty round.  Rounding DOWN (<= 1024: two full rounds): 0.563 -> 0.525 ms (123 k points, N = 264) and 0.900 ->
+    // 0.778 ms (55 k points, N = 573; 46.7 TFLOP/s = 59 % of the FP64-MFMA peak); 768 / 1536 are worse, 2048 equal, 4096 better
+    // for N = 264 (0.485) and worse for N = 573 (0.836: 130 MB of split atomics) -- tools/vmat_ab.py.  Other tile shapes
+    // (64x64 / 128x64 / 64x128 / 128x128 outputs, 16-64 points per LDS stage) were within +-10 % of this kernel, none better on both.
+    const int64_t wgs = c->opt_vmat_wgs > 0 ? c->opt_vmat_wgs : 1024;
+    int64_t nsplit = c->opt_vmat_wgs >= 0 ? std::max<int64_t>(1, std::min<int64_t>((ng + 511) / 512, wgs / (nt * nt)))
+                                          : std::max<int64_t>(1, std::min<int64_t>((ng + 511) / 512, (1024 + nt * nt - 1) / (nt * nt)));
     int64_t kchunk = ((ng + nsplit - 1) / nsplit + VM_KS - 1) / VM_KS * VM_KS;
     nsplit = (ng + kchunk - 1) / kchunk;
     hipLaunchKernelGGL(xc_vmat_kernel, dim3(nt, nt, (unsigned)nsplit), dim3(256), 0, (hipStream_t)stream, d_ao0, d_aow, c->nao, ng, kchunk, d_vmat);

@@ -98,7 +98,7 @@ class RKS(RHF):
         ng = coords.shape[0]
         lo, hi = self._grid_range(ng)
         # grid block: as large as a ~1.5 GB working set allows (fewer launches for small molecules), at least grid_block
-        B = max(self.grid_block, int(1.5e9 / (48.0 * n)) // 1024 * 1024)
+        B = max(self.grid_block, int(self._xc_block_bytes() / (48.0 * n)) // 1024 * 1024)
         if hi - lo <= 1.5 * B:
             B = max(hi - lo, 1)   # no small remainder block: its kernels would be pure launch latency (0.15 ms per build on benzene/cc-pVTZ)
         else:                     # equal blocks instead of full ones plus a short tail
@@ -141,6 +141,16 @@ class RKS(RHF):
                 for k in (1, 2, 3):
                     eng.xc_vmat(ao[k], wv[4] * ao[k], vmat)
         return hyb
+
+    # Working set of one grid block (AO values + weighted AOs).  The per-point kernels are one thread per grid point: a block of
+    # 55 k points (1.5 GB at N = 573, the round-1 size) is 216 workgroups for 256 CUs -- one wave per SIMD for a latency-bound
+    # kernel.  4 GB (ibuprofen/def2-TZVP: 3 blocks of 108 k points instead of 7): RKS cycle 29.5 -> 28.0 ms; 12 GB: 28.2 ms
+    # (tools/rks_cycle.py; env MI355_XC_BLOCK_GB overrides for such sweeps).
+    xc_block_gb = 4.0
+
+    def _xc_block_bytes(self):
+        import os
+        return float(os.environ.get("MI355_XC_BLOCK_GB", self.xc_block_gb)) * 1e9
 
     xc_lowrank = True   # inside the SCF loop: rho from occupied-orbital values (D = Z Z^T) instead of D.ao
     xc_lowrank_min_nao = 128   # below this the dozen small launches of the factorisation cost more than the D.ao GEMM (CH3/cc-pVTZ UKS: 2.9 -> 3.4 ms)

@@ -43,6 +43,8 @@ class UKS(UHF):
             self._log(4, f"XC grid: {self.grids.size} points (level {self.grids.level})")
 
     _ao_cache_for = RKS._ao_cache_for
+    xc_block_gb = RKS.xc_block_gb
+    _xc_block_bytes = RKS._xc_block_bytes
     _lowrank_factor = RKS._lowrank_factor
     xc_lowrank, xc_lowrank_min_nao = True, RKS.xc_lowrank_min_nao
     _grid_range = RKS._grid_range
@@ -64,7 +66,7 @@ class UKS(UHF):
         coords, weights = self.grids.coords, self.grids.weights
         ng = coords.shape[0]
         lo, hi = self._grid_range(ng)
-        B = max(self.grid_block, int(1.5e9 / (64.0 * n)) // 1024 * 1024)
+        B = max(self.grid_block, int(self._xc_block_bytes() / (64.0 * n)) // 1024 * 1024)
         cache = self._ao_cache_for(n, hi - lo, 4 if gga else 1)
         # spin densities declared projectors by the fast UHF/UKS loop (`_xc_projector_pair`): D_s = Z_s Z_s^T without orbitals
         Zps = [None, None]

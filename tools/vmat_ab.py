@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""xc_vmat split counts (option vmat_wgs; -1 = the round-1 formula) on random AO blocks: time per call and deviation from the first.
+  python tools/vmat_ab.py [benzene|ibuprofen]"""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "computational-chemistry-ai_amd", "python"))
+import numpy as np, torch
+from mi355scf.mole import Mole
+from mi355scf.engine import Engine
+from mi355scf import smiles_fixtures, fixtures
+name = sys.argv[1] if len(sys.argv) > 1 else "benzene"
+if name == "benzene":
+    mol = Mole(atom=fixtures.BENZENE, basis="cc-pVTZ", verbose=0).build(); ng = 123158
+else:
+    sym, xyz = smiles_fixtures.TABLE["CC(C)Cc1ccc(cc1)C(C)C(=O)O"]()
+    mol = Mole(atom="; ".join(f"{s} {x:.6f} {y:.6f} {z:.6f}" for s, (x, y, z) in zip(sym, xyz)), basis="def2-TZVP", verbose=0).build(); ng = 54 * 1024
+eng = Engine(mol)
+n = mol.nao
+g = torch.Generator(device="cuda").manual_seed(1)
+ao = torch.randn(n, ng, generator=g, dtype=torch.float64, device="cuda")
+aow = torch.randn(n, ng, generator=g, dtype=torch.float64, device="cuda")
+ref = None
+for _ in range(30): eng.xc_vmat(ao, aow, torch.zeros(n, n, dtype=torch.float64, device="cuda"))   # clocks
+tile = 0
+for wgs in (-1, 0, 512, 768, 1536, 2048, 4096, -1, 0):
+    eng.set_option("vmat_wgs", wgs)
+    v = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    eng.xc_vmat(ao, aow, v)
+    if ref is None: ref = v.clone()
+    dev = float((v - ref).abs().max() / ref.abs().max())
+    for _ in range(3): eng.xc_vmat(ao, aow, v)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(20): eng.xc_vmat(ao, aow, v)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 20
+    print(json.dumps(dict(case=name, n=n, ng=ng, tile=tile, wgs=wgs, ms=round(ms, 4), tflops=round(2.0 * ng * n * n / ms / 1e9, 1), rel_dev=dev)), flush=True)
