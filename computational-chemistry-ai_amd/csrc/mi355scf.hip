@@ -2307,6 +2307,11 @@ __device__ __forceinline__ d2_t jk_load_chunk(const d2_t *__restrict__ tile, int
 }
 
 // Digestion of one tile by one wave: 32 chunk loads per lane, six contractions per value, per-tile outputs.
+// Register budget (J+K, gfx950 ISA): 256 VGPRs + 158 AGPRs, one wave per SIMD; 128 of them are the run-wide K_JL accumulators.
+// The compiled tile body is ~1 700 instructions for 384 FMAs: each 16-byte load costs 9 (exec mask for partial blocks, the
+// row stride read back from a spilled SGPR, a 64-bit multiply-add), the rest is AGPR traffic, selects and ds_bpermute of the
+// reduce-scatters.  A specialisation for full 8x8x8x8 tiles (immediate offsets, no masks) let the scheduler hoist all 32 loads,
+// which pushed the kernel to 512 registers and 2.23 ms (from 0.78) -- rejected; any rewrite has to bound the loads in flight.
 template <bool WITH_J, bool WITH_K, bool NT, bool DIJ, bool DKL>
 __device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, const int i, const int k, const int I0, const int J0,
                                                const int K0, const int L0, const int ld, const int bk, const int64_t toff,
