@@ -3341,6 +3341,49 @@ __global__ __launch_bounds__(256) void xc_rho_mo_kernel(const double *psi, int n
     if (tau) tau[g] = 0.5 * tk;
 }
 
+// Warm start of the low-rank (Nystrom) factor of the projector, one launch instead of ~14 elementwise / reduction launches:
+//   good  = every element of Zt [nocc][n] is finite and the Cholesky factorisation reported info == 0
+//   scale = 1 / sqrt(max(sum_c Zt[0][c]^2, 1e-300))
+//   G[r][c] = good ? 0.05 G0[r][c] + scale Zt[c][r] : G0[r][c]           (G, G0: [n][nocc])
+// Every workgroup recomputes the two reductions in the same fixed order (the factor is a few hundred KB in L2) and writes its
+// share of G: deterministic, no second launch.  (dft.RKS._lowrank_factor; PySCF has no counterpart -- it takes the occupied
+// orbitals from the diagonalisation [MEM: numint.eval_rho2].)
+__global__ __launch_bounds__(256) void nystrom_warm_kernel(const double *__restrict__ Zt, const int *__restrict__ info,
+                                                           const double *__restrict__ G0, double *__restrict__ G, int nocc, int n)
+{
+    __shared__ double sh_s[4];
+    __shared__ int sh_f[4];
+    const int t = threadIdx.x;
+    const size_t tot = (size_t)nocc * n;
+    int finite = 1;
+    double s = 0.0;
+    for (size_t idx = t; idx < tot; idx += 256) {
+        const double v = Zt[idx];
+        finite &= (int)isfinite(v);
+        if (idx < (size_t)n) s = fma(v, v, s);     // row 0
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); finite &= __shfl_xor(finite, o); }
+    if ((t & 63) == 0) { sh_s[t >> 6] = s; sh_f[t >> 6] = finite; }
+    __syncthreads();
+    const double ssum = (sh_s[0] + sh_s[1]) + (sh_s[2] + sh_s[3]);
+    const bool good = (sh_f[0] & sh_f[1] & sh_f[2] & sh_f[3]) && info[0] == 0;
+    const double scale = 1.0 / sqrt(fmax(ssum, 1e-300));
+    for (size_t idx = (size_t)blockIdx.x * 256 + t; idx < tot; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / nocc), c = (int)(idx - (size_t)r * nocc);
+        G[idx] = good ? fma(scale, Zt[(size_t)c * n + r], 0.05 * G0[idx]) : G0[idx];
+    }
+}
+
+extern "C" int mi_nystrom_warm(mi_ctx *c, const double *d_Zt, const int *d_info, const double *d_G0, double *d_G, int nocc, int n,
+                               void *stream)
+{
+    if (!c || !d_Zt || !d_info || !d_G0 || !d_G || nocc < 1 || n < 1) return fail("mi_nystrom_warm: bad argument");
+    const int nb = (int)std::min<size_t>(64, ((size_t)nocc * n + 255) / 256);
+    hipLaunchKernelGGL(nystrom_warm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d_Zt, d_info, d_G0, d_G, nocc, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mi_xc_rho_mo(mi_ctx *c, const double *d_psi, int nocc, int64_t ng, int deriv, double *d_rho, double *d_tau, void *stream)
 {
     if (!c || !d_psi || !d_rho || nocc < 1 || (d_tau && !deriv)) return fail("mi_xc_rho_mo: bad argument");

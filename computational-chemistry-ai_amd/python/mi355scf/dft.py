@@ -108,8 +108,12 @@ class RKS(RHF):
         Zt = self._occ_factor(dm)
         if Zt is not None:   # [nao, ldz] with the orbital index fastest, zero-padded to the kernel's chunk (24 GGA / 32 LDA)
             ch = 24 if gga else 32
-            Zp = torch.zeros(n, (Zt.shape[0] + ch - 1) // ch * ch, dtype=torch.float64, device=Zt.device)
-            Zp[:, :Zt.shape[0]] = Zt.T
+            ldz = (Zt.shape[0] + ch - 1) // ch * ch
+            Zp = getattr(self, "_zp_buf", None)      # persistent: the padding columns are zeroed once, not every cycle
+            if Zp is None or Zp.shape != (n, ldz) or Zp.device != Zt.device or self._zp_nocc != Zt.shape[0]:
+                Zp = self._zp_buf = torch.zeros(n, ldz, dtype=torch.float64, device=Zt.device)
+                self._zp_nocc = Zt.shape[0]
+            Zp[:, :Zt.shape[0]].copy_(Zt.T)
         for ib, p0 in enumerate(range(lo, hi, B)):
             p1 = min(p0 + B, hi)
             c, w = coords[p0:p1], weights[p0:p1]
@@ -190,9 +194,15 @@ class RKS(RHF):
         Zp_t = torch.linalg.solve_triangular(R, W.T, upper=False)   # R^-1 W^T: dmo = Zp Zp^T
         # (a cycle whose projector was not valid -- speculative purification, checked later by the host -- must not poison
         # the warm start: keep the Gaussian matrix unless the factor is finite and the factorisation succeeded)
-        good = torch.isfinite(Zp_t).all() & (_info == 0)
-        scale = 1.0 / torch.sqrt(torch.clamp(torch.sum(Zp_t[0] * Zp_t[0]), min=1e-300))    # columns of Zp to unit norm
-        st[(key, "G")] = torch.where(good, G0 * 0.05 + Zp_t.T * scale, G0)
+        # ONE launch (`nystrom_warm_kernel`) for what used to be ~14 elementwise / reduction launches per cycle:
+        #   good = isfinite(Zp_t).all() & (info == 0); scale = 1 / |Zp_t[0]|; G <- good ? 0.05 G0 + scale Zp_t^T : G0
+        if not Zp_t.is_contiguous():
+            Zp_t = Zp_t.contiguous()
+        bufs = st.get((key, "Gbuf"))
+        if bufs is None or bufs[0].shape != G0.shape or bufs[0].device != G0.device:
+            bufs = st[(key, "Gbuf")] = [torch.empty_like(G0), torch.empty_like(G0)]
+        Gn = bufs[0] if G.data_ptr() != bufs[0].data_ptr() else bufs[1]     # never the matrix this cycle's W was formed from
+        st[(key, "G")] = self.engine.nystrom_warm(Zp_t, _info, G0, Gn)
         return Zp_t @ self._Linv                            # (L^-T Zp)^T
 
     def _ao_cache_for(self, nao, npts, ncomp):

@@ -90,6 +90,7 @@ def lib():
         L.mi_xc_eval_mgga.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, i64, vp, vp, vp]
         L.mi_xc_eval_mgga_spin.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.mi_xc_vmat.argtypes = [vp, vp, vp, i64, vp, vp]
+        L.mi_nystrom_warm.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_sp2_iterate.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, ctypes.POINTER(vp), vp]
@@ -391,6 +392,14 @@ class Engine:
                                           rhob.data_ptr(), taua.data_ptr(), taub.data_ptr(), weights.data_ptr(), ng, exc.data_ptr(),
                                           wva.data_ptr(), wvb.data_ptr(), self._stream()))
         return exc, wva, wvb
+
+    def nystrom_warm(self, Zt, info, G0, G):
+        """G[n, nocc] = 0.05 G0 + Zt^T / |Zt[0]| if the factor Zt [nocc, n] is finite and `info` (int32 device scalar of
+        cholesky_ex) is 0, else G0 -- one launch (dft.RKS._lowrank_factor)."""
+        assert Zt.is_contiguous() and G0.is_contiguous() and G.is_contiguous() and info.dtype == torch.int32
+        _check(lib().mi_nystrom_warm(self._h, Zt.data_ptr(), info.data_ptr(), G0.data_ptr(), G.data_ptr(), Zt.shape[0], Zt.shape[1],
+                                     self._stream()))
+        return G
 
     def xc_aow(self, ao, wv, gga=True):
         ng = ao.shape[-1]

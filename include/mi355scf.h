@@ -223,6 +223,10 @@ int mi_xc_rho(mi_ctx *ctx, const double *d_ao, const double *d_C, int64_t ng, in
  * (numint.eval_rho2 [MEM], what PySCF uses when mo_coeff / mo_occ are known): rho = sum psi^2, grad rho = 2 sum psi grad psi,
  * and (d_tau non-null, deriv = 1) the kinetic-energy density tau = 1/2 sum |grad psi|^2 of the meta-GGAs. */
 int mi_xc_rho_mo(mi_ctx *ctx, const double *d_psi, int nocc, int64_t ng, int deriv, double *d_rho, double *d_tau, void *stream);
+/* Warm start of the low-rank factor of the projector (project-defined; no reference counterpart): d_G[n][nocc] =
+ * good ? 0.05 d_G0 + scale d_Zt^T : d_G0, good = (all of d_Zt[nocc][n] finite) && *d_info == 0, scale = 1 / |row 0 of d_Zt|. */
+int mi_nystrom_warm(mi_ctx *ctx, const double *d_Zt, const int *d_info, const double *d_G0, double *d_G, int nocc, int n,
+                    void *stream);
 /* Both steps fused (psi never stored): d_Zp[nao][ldz] = Z with the orbital index fastest, zero-padded to ldz = a multiple of
  * 24 (deriv = 1) or 32 (deriv = 0) columns; d_ao as in mi_xc_rho. */
 int mi_xc_rho_lowrank(mi_ctx *ctx, const double *d_ao, const double *d_Zp, int ldz, int64_t ng, int deriv, double *d_rho,
