@@ -3374,6 +3374,59 @@ __global__ __launch_bounds__(256) void nystrom_warm_kernel(const double *__restr
     }
 }
 
+// Cholesky factor of M = G^T X G [nocc][nocc] (lower, row-major) and the triangular solve Zt = R^-1 W^T in ONE launch (replaces
+// torch.linalg.cholesky_ex + solve_triangular: potf2, reset_info, iota, triu and trsm launches, 48 us per cycle at nocc = 21).
+// W: [n][nocc] row-major; Zt: [nocc][n].  Every workgroup of 64 threads factors M itself in LDS (nocc <= 64: at most 90 k flops)
+// and then solves for its 64 columns, row by row: z_i = (w_i - sum_{j<i} R_ij z_j) / R_ii with the earlier z_j re-read from the
+// output (the thread's own stores).  info[0] = 0, or k + 1 for the first non-positive / non-finite pivot (LAPACK's convention);
+// in that case Zt is filled with NaN so that the caller's electron count fails its check.
+#define NYS_MAXOCC 64
+__global__ __launch_bounds__(64) void nystrom_factor_kernel(const double *__restrict__ M, const double *__restrict__ W, int n, int nocc,
+                                                            double *Zt, int *__restrict__ info)
+{
+    __shared__ double L[NYS_MAXOCC][NYS_MAXOCC + 1];
+    __shared__ int fail_at;
+    const int t = threadIdx.x;
+    for (int idx = t; idx < nocc * nocc; idx += 64) { const int r = idx / nocc, c = idx - r * nocc; L[r][c] = M[idx]; }
+    if (t == 0) fail_at = 0;
+    __syncthreads();
+    for (int k = 0; k < nocc; k++) {
+        if (t == 0) {
+            const double d = L[k][k];
+            if (!(d > 0.0) || !isfinite(d)) { if (fail_at == 0) fail_at = k + 1; L[k][k] = 1.0; }
+            else L[k][k] = sqrt(d);
+        }
+        __syncthreads();
+        if (t > k && t < nocc) L[t][k] /= L[k][k];
+        __syncthreads();
+        const int m = nocc - k - 1;                       // trailing block (i, j), k < j <= i < nocc
+        for (int idx = t; idx < m * m; idx += 64) {
+            const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+            if (j <= i) L[i][j] = fma(-L[i][k], L[j][k], L[i][j]);
+        }
+        __syncthreads();
+    }
+    const bool failed = fail_at != 0;
+    if (blockIdx.x == 0 && t == 0) info[0] = fail_at;
+    const int c = blockIdx.x * 64 + t;
+    if (c >= n) return;
+    const double *w = W + (size_t)c * nocc;
+    for (int i = 0; i < nocc; i++) {
+        double z = w[i];
+        for (int j = 0; j < i; j++) z = fma(-L[i][j], Zt[(size_t)j * n + c], z);
+        Zt[(size_t)i * n + c] = failed ? __builtin_nan("") : z / L[i][i];
+    }
+}
+
+extern "C" int mi_nystrom_factor(mi_ctx *c, const double *d_M, const double *d_W, int n, int nocc, double *d_Zt, int *d_info, void *stream)
+{
+    if (!c || !d_M || !d_W || !d_Zt || !d_info || n < 1 || nocc < 1) return fail("mi_nystrom_factor: bad argument");
+    if (nocc > NYS_MAXOCC) return fail("mi_nystrom_factor: at most %d columns", NYS_MAXOCC);
+    hipLaunchKernelGGL(nystrom_factor_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_M, d_W, n, nocc, d_Zt, d_info);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mi_nystrom_warm(mi_ctx *c, const double *d_Zt, const int *d_info, const double *d_G0, double *d_G, int nocc, int n,
                                void *stream)
 {

@@ -190,8 +190,11 @@ class RKS(RHF):
         G = st[(key, "G")]
         W = dmo @ G
         M = G.T @ W
-        R, _info = torch.linalg.cholesky_ex(M)             # no host sync; a failed factorisation shows up as a wrong N_elec
-        Zp_t = torch.linalg.solve_triangular(R, W.T, upper=False)   # R^-1 W^T: dmo = Zp Zp^T
+        if nocc <= self.engine.NYSTROM_MAX_OCC and W.is_contiguous() and M.is_contiguous():
+            Zp_t, _info = self.engine.nystrom_factor(M, W)    # Cholesky + triangular solve in one launch
+        else:
+            R, _info = torch.linalg.cholesky_ex(M)             # no host sync; a failed factorisation shows up as a wrong N_elec
+            Zp_t = torch.linalg.solve_triangular(R, W.T, upper=False)   # R^-1 W^T: dmo = Zp Zp^T
         # (a cycle whose projector was not valid -- speculative purification, checked later by the host -- must not poison
         # the warm start: keep the Gaussian matrix unless the factor is finite and the factorisation succeeded)
         # ONE launch (`nystrom_warm_kernel`) for what used to be ~14 elementwise / reduction launches per cycle:

@@ -91,6 +91,7 @@ def lib():
         L.mi_xc_eval_mgga_spin.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.mi_xc_vmat.argtypes = [vp, vp, vp, i64, vp, vp]
         L.mi_nystrom_warm.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]
+        L.mi_nystrom_factor.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_sp2_iterate.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, ctypes.POINTER(vp), vp]
@@ -392,6 +393,20 @@ class Engine:
                                           rhob.data_ptr(), taua.data_ptr(), taub.data_ptr(), weights.data_ptr(), ng, exc.data_ptr(),
                                           wva.data_ptr(), wvb.data_ptr(), self._stream()))
         return exc, wva, wvb
+
+    NYSTROM_MAX_OCC = 64
+
+    def nystrom_factor(self, M, W, Zt=None, info=None):
+        """(Zt [nocc, n] = R^-1 W^T, info) with M [nocc, nocc] = R R^T and W [n, nocc]: Cholesky factorisation and triangular
+        solve in one launch (nocc <= NYSTROM_MAX_OCC)."""
+        n, nocc = W.shape
+        assert M.is_contiguous() and W.is_contiguous() and M.shape == (nocc, nocc) and nocc <= self.NYSTROM_MAX_OCC
+        if Zt is None:
+            Zt = self._new(nocc, n)
+        if info is None:
+            info = torch.empty((), dtype=torch.int32, device=self.device)
+        _check(lib().mi_nystrom_factor(self._h, M.data_ptr(), W.data_ptr(), n, nocc, Zt.data_ptr(), info.data_ptr(), self._stream()))
+        return Zt, info
 
     def nystrom_warm(self, Zt, info, G0, G):
         """G[n, nocc] = 0.05 G0 + Zt^T / |Zt[0]| if the factor Zt [nocc, n] is finite and `info` (int32 device scalar of

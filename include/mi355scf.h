@@ -227,6 +227,9 @@ int mi_xc_rho_mo(mi_ctx *ctx, const double *d_psi, int nocc, int64_t ng, int der
  * good ? 0.05 d_G0 + scale d_Zt^T : d_G0, good = (all of d_Zt[nocc][n] finite) && *d_info == 0, scale = 1 / |row 0 of d_Zt|. */
 int mi_nystrom_warm(mi_ctx *ctx, const double *d_Zt, const int *d_info, const double *d_G0, double *d_G, int nocc, int n,
                     void *stream);
+/* d_Zt[nocc][n] = R^-1 d_W^T with d_M[nocc][nocc] = R R^T (lower Cholesky factor), d_W[n][nocc]; *d_info = 0 or the 1-based index
+ * of the first bad pivot (then d_Zt is NaN).  nocc <= 64.  Stands in for torch.linalg.cholesky_ex + solve_triangular. */
+int mi_nystrom_factor(mi_ctx *ctx, const double *d_M, const double *d_W, int n, int nocc, double *d_Zt, int *d_info, void *stream);
 /* Both steps fused (psi never stored): d_Zp[nao][ldz] = Z with the orbital index fastest, zero-padded to ldz = a multiple of
  * 24 (deriv = 1) or 32 (deriv = 0) columns; d_ao as in mi_xc_rho. */
 int mi_xc_rho_lowrank(mi_ctx *ctx, const double *d_ao, const double *d_Zp, int ldz, int64_t ng, int deriv, double *d_rho,
