@@ -5704,6 +5704,50 @@ extern "C" int mi_fock_energy(mi_ctx *c, const double *d_h, const double *d_J, c
     return 0;
 }
 
+// J/K digestion and Fock / energy assembly without the intermediate J and K matrices (single rank, resident tiles): the
+// epilogue reads the padded accumulators directly,
+//   J = 2 (Jacc + Jacc^T), K = Kacc + Kacc^T, F = h + J - kscale K (+ V + V^T for an UNsymmetrised XC matrix V),
+//   part[block] = this block's share of sum D (h + 0.5 (J - kscale K))      (same fixed-order partials as fock_energy_kernel)
+// -- one launch instead of finalize_jk_kernel + (V + V^T) + fock_energy_kernel, and 2 N^2 doubles less written and re-read.
+__global__ __launch_bounds__(256) void finalize_fock_kernel(const double *Jacc, const double *Kacc, int ld, const double *h,
+                                                            const double *Vun, const double *D, double kscale, int nao, double *F,
+                                                            double *part)
+{
+    __shared__ double sh[4];
+    const size_t nn = (size_t)nao * nao, idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double e = 0.0;
+    if (idx < nn) {
+        const int r = (int)(idx / nao), c = (int)(idx - (size_t)r * nao);
+        const double j = 2.0 * (Jacc[(size_t)r * ld + c] + Jacc[(size_t)c * ld + r]);
+        const double k = Kacc ? Kacc[(size_t)r * ld + c] + Kacc[(size_t)c * ld + r] : 0.0;
+        const double v2 = j - (Kacc ? kscale * k : 0.0);
+        const double hh = h[idx];
+        F[idx] = hh + v2 + (Vun ? Vun[idx] + Vun[(size_t)c * nao + r] : 0.0);
+        e = D[idx] * (hh + 0.5 * v2);
+    }
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+extern "C" int mi_build_fock(mi_ctx *c, const double *d_D, const double *d_h, const double *d_Vun, int with_k, double kscale, double *d_F,
+                             double *d_part, void *stream)
+{
+    if (!c || !d_D || !d_h || !d_F || !d_part) return fail("mi_build_fock: null argument");
+    if (!c->eri_ready) return fail("mi_build_fock: call mi_eri_prepare first");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nn = (size_t)c->nao * c->nao, pp = (size_t)c->ldp * c->ldp;
+    hipLaunchKernelGGL(pad_density_clear_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->d_Jacc,
+                       with_k ? c->d_Kacc : nullptr, c->nao, c->ldp);
+    if (launch_jk(c, true, with_k != 0, st)) return -1;
+    hipLaunchKernelGGL(finalize_fock_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, c->d_Jacc, with_k ? c->d_Kacc : nullptr,
+                       c->ldp, d_h, d_Vun, d_D, kscale, c->nao, d_F, d_part);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // E = M - M^T and part[block] = this block's share of sum E^2 (fixed-order partials, see fock_energy_kernel)
 __global__ __launch_bounds__(256) void commutator_norm_kernel(const double *M, int n, double *E, double *part)
 {

@@ -262,6 +262,15 @@ class RKS(RHF):
         nn = n * n
         hyb = parse_xc(self.xc)[0]
         with_k = abs(hyb) > 1e-12
+        if self._fused_fock_ok(dm):
+            # single rank, resident tiles: no collective, so J and K need not exist -- the fused epilogue of the J/K pass adds
+            # h, the unsymmetrised XC matrix and its transpose, and writes the energy partials (mi_build_fock)
+            buf = torch.zeros(nn + 2, dtype=torch.float64, device=eng.device)
+            V, tail = buf[:nn].view(n, n), buf[nn:]
+            self._nr_rks_raw(dm, V, tail)
+            self._nelec_grid = tail[0]
+            F = eng.build_fock(dm, self._h1, 0.5 * hyb, torch.empty_like(dm), part, with_k=with_k, vxc_unsym=V)
+            return F, tail[0:2]
         nmat = 3 if with_k else 2
         buf = torch.zeros(nmat * nn + 2, dtype=torch.float64, device=eng.device)
         J = buf[:nn].view(n, n)

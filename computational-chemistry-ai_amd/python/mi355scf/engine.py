@@ -91,6 +91,7 @@ def lib():
         L.mi_xc_eval_mgga_spin.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.mi_xc_vmat.argtypes = [vp, vp, vp, i64, vp, vp]
         L.mi_nystrom_warm.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]
+        L.mi_build_fock.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_double, vp, vp, vp]
         L.mi_nystrom_factor.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
         L.mi_sp2_update.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
@@ -473,6 +474,18 @@ class Engine:
         _check(lib().mi_sp2_iterate_planned(self._h, F.data_ptr(), A.data_ptr(), B.data_ptr(), nit, _dp(coef), float(out_scale),
                                             tr.data_ptr(), ctypes.byref(out), ctypes.byref(res), self._stream()))
         return (A if res.value == A.data_ptr() else B), (out.value - tr.data_ptr()) // 8
+
+    def build_fock(self, D, h, kscale, F, part, with_k=True, vxc_unsym=None):
+        """F = h + J(D) - kscale K(D) (+ V + V^T) and the energy partial sums in `part`, without forming J and K (single rank,
+        resident tiles): pad -> J/K digestion -> fused finalize."""
+        if not self.eri_ready:
+            self.prepare_eri()
+        assert D.is_contiguous() and F.is_contiguous() and part.numel() == self.reduce_blocks and part.is_contiguous()
+        assert vxc_unsym is None or vxc_unsym.is_contiguous()
+        with torch.cuda.device(self.device):
+            _check(lib().mi_build_fock(self._h, D.data_ptr(), h.data_ptr(), vxc_unsym.data_ptr() if vxc_unsym is not None else None,
+                                       int(bool(with_k)), float(kscale), F.data_ptr(), part.data_ptr(), self._stream()))
+        return F
 
     def fock_energy(self, h, J, K, Vxc, D, kscale, F, part):
         """F = h + J - kscale K (+ Vxc); part[reduce_blocks] = partial sums of E_elec (add them in index order)."""

@@ -394,10 +394,18 @@ class SCF:
         """F = h + veff(D) on device; `part` receives the fixed-order partial sums of E_elec(D) (fused kernel).  Returns
         (F, extra): `extra` is None or a device tensor whose LAST element is added to the energy (E_xc); RKS passes
         [N_elec on the grid, E_xc] so that the host can also validate the quadrature of the cycle.  Overridden by RKS."""
+        if self._fused_fock_ok(dm):
+            return self.engine.build_fock(dm, self._h1, 0.5, torch.empty_like(dm), part), None
         J, K = self._jk(dm)
         F = torch.empty_like(J)
         self.engine.fock_energy(self._h1, J, K, None, dm, 0.5, F, part)
         return F, None
+
+    fused_fock = True   # single rank, resident tiles: F and the energy partials straight from the J/K accumulators (mi_build_fock)
+
+    def _fused_fock_ok(self, dm):
+        return (self.fused_fock and self._nranks == 1 and self._stream_groups <= 1 and getattr(self, "with_df", None) is None
+                and dm.dim() == 2 and dm.is_contiguous())
 
     @staticmethod
     def _sp2_traces(tr_host):

@@ -223,6 +223,13 @@ int mi_xc_rho(mi_ctx *ctx, const double *d_ao, const double *d_C, int64_t ng, in
  * (numint.eval_rho2 [MEM], what PySCF uses when mo_coeff / mo_occ are known): rho = sum psi^2, grad rho = 2 sum psi grad psi,
  * and (d_tau non-null, deriv = 1) the kinetic-energy density tau = 1/2 sum |grad psi|^2 of the meta-GGAs. */
 int mi_xc_rho_mo(mi_ctx *ctx, const double *d_psi, int nocc, int64_t ng, int deriv, double *d_rho, double *d_tau, void *stream);
+/* Fock matrix and energy partial sums straight from the J/K accumulators (single rank, resident tiles; the matrices J and K are
+ * never formed): d_F = d_h + J - kscale K (+ d_Vun + d_Vun^T when d_Vun, an UNsymmetrised XC matrix, is given); d_part as in
+ * mi_fock_energy.  with_k = 0: Coulomb only.  Same kernels as mi_build_jk for the digestion.
+ * Replaces (with mi_build_jk / mi_fock_energy): get_veff + get_fock of the SCF classes, reached from mf.kernel(),
+ * templates/calculate_energy.py:205. */
+int mi_build_fock(mi_ctx *ctx, const double *d_D, const double *d_h, const double *d_Vun, int with_k, double kscale, double *d_F,
+                  double *d_part, void *stream);
 /* Warm start of the low-rank factor of the projector (project-defined; no reference counterpart): d_G[n][nocc] =
  * good ? 0.05 d_G0 + scale d_Zt^T : d_G0, good = (all of d_Zt[nocc][n] finite) && *d_info == 0, scale = 1 / |row 0 of d_Zt|. */
 int mi_nystrom_warm(mi_ctx *ctx, const double *d_Zt, const int *d_info, const double *d_G0, double *d_G, int nocc, int n,
