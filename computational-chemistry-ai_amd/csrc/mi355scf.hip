@@ -319,6 +319,7 @@ struct mi_ctx {
     int opt_sp2_persist = 0; // planned purification as ONE resident launch with grid barriers (1: release/acquire fences, 2: write-through
                              // stores + L2-bypassing loads) -- measured SLOWER than one launch per pass (0), see sp2_plan_persist_kernel
     unsigned *d_sp2_bar = nullptr; // [0] arrival counter (monotonic), [1] abort tag
+    double *d_xt_scratch = nullptr; // xc_tail_kernel: per-workgroup partials + ticket
     unsigned sp2_bar_base = 0, sp2_tag = 0;
     int n_cu = 0;
 };
@@ -472,7 +473,7 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     hipSetDevice(c->device);
     free_eri(c);
     void *ptrs[] = {c->d_env, c->d_bas, c->d_atm, c->d_shell_ao, c->d_c2s, c->d_rys_cheb, c->d_herm_r, c->d_herm_w,
-                    c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red, c->d_shell_xyz, c->d_sp2_bar};
+                    c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red, c->d_shell_xyz, c->d_sp2_bar, c->d_xt_scratch};
     for (void *p : ptrs) if (p) hipFree(p);
     delete c;
 }
@@ -3372,6 +3373,65 @@ __global__ __launch_bounds__(256) void nystrom_warm_kernel(const double *__restr
         const int r = (int)(idx / nocc), c = (int)(idx - (size_t)r * nocc);
         G[idx] = good ? fma(scale, Zt[(size_t)c * n + r], 0.05 * G0[idx]) : G0[idx];
     }
+}
+
+// Quadrature sums of one grid block in ONE launch: tail[q] += sum_g w[g] v_q[g] for q < nv (N_elec, E_xc; the two spin counts
+// and E_xc for UKS) -- replaces nv rocBLAS dots (two launches each) and nv adds.  Deterministic: every workgroup reduces a
+// contiguous chunk in a fixed tree and stores its partials; the workgroup that arrives LAST (ticket from an agent-scope atomic,
+// fences around it) adds all partials in index order.  scratch: [XT_MAXWG][3] doubles + the ticket counter, owned by the context.
+#define XT_MAXWG 256
+struct XcTailArgs { const double *w; const double *v[3]; int nv; int64_t ng; double *tail; double *scratch; unsigned *ticket; };
+__global__ __launch_bounds__(256) void xc_tail_kernel(XcTailArgs A)
+{
+    __shared__ double sh[3][4];
+    __shared__ int last;
+    const int t = threadIdx.x, nwg = gridDim.x;
+    const int64_t per = (A.ng + nwg - 1) / nwg, lo = per * blockIdx.x, hi = min(A.ng, lo + per);
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int64_t g = lo + t; g < hi; g += 256) {
+        const double wg = A.w[g];
+#pragma unroll
+        for (int q = 0; q < 3; q++) if (q < A.nv) s[q] = fma(wg, A.v[q][g], s[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_xor(s[q], o);
+        if ((t & 63) == 0) sh[q][t >> 6] = s[q];
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (int q = 0; q < A.nv; q++) A.scratch[blockIdx.x * 3 + q] = (sh[q][0] + sh[q][1]) + (sh[q][2] + sh[q][3]);
+        __threadfence();                                             // partials visible before the ticket
+        const unsigned k = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (k == (unsigned)nwg - 1u);
+        if (last) {
+            __threadfence();
+            for (int q = 0; q < A.nv; q++) {
+                double tot = 0.0;
+                for (int b = 0; b < nwg; b++) tot += __hip_atomic_load(A.scratch + b * 3 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                A.tail[q] += tot;
+            }
+            __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream order)
+        }
+    }
+}
+
+extern "C" int mi_xc_tail(mi_ctx *c, const double *d_w, const double *d_v0, const double *d_v1, const double *d_v2, int64_t ng,
+                          double *d_tail, void *stream)
+{
+    if (!c || !d_w || !d_v0 || !d_tail || ng < 1) return fail("mi_xc_tail: bad argument");
+    if (!c->d_xt_scratch) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipMalloc(&c->d_xt_scratch, sizeof(double) * (XT_MAXWG * 3 + 1)));
+        HIPCHK(hipMemsetAsync(c->d_xt_scratch, 0, sizeof(double) * (XT_MAXWG * 3 + 1), (hipStream_t)stream));
+    }
+    XcTailArgs A{};
+    A.w = d_w; A.v[0] = d_v0; A.v[1] = d_v1; A.v[2] = d_v2; A.nv = d_v2 ? 3 : (d_v1 ? 2 : 1); A.ng = ng; A.tail = d_tail;
+    A.scratch = c->d_xt_scratch; A.ticket = reinterpret_cast<unsigned *>(c->d_xt_scratch + XT_MAXWG * 3);
+    const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(XT_MAXWG, (ng + 2047) / 2048));
+    hipLaunchKernelGGL(xc_tail_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, A);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // Cholesky factor of M = G^T X G [nocc][nocc] (lower, row-major) and the triangular solve Zt = R^-1 W^T in ONE launch (replaces

@@ -137,8 +137,7 @@ class RKS(RHF):
                 e, wv = eng.xc_eval_mgga(terms, rho, tau, w)
             else:
                 e, wv = eng.xc_eval(terms, rho, w, gga)
-            tail[0] += torch.dot(w, rho[0])
-            tail[1] += torch.dot(w, e)
+            eng.xc_tail(w, (rho[0], e), tail)     # tail[0] += w.rho (N_elec), tail[1] += w.e (E_xc): one deterministic launch
             aow = eng.xc_aow(ao, wv, gga)
             eng.xc_vmat(ao[0], aow, vmat)      # vmat += ao0 . aow^T  (split-K FP64 MFMA kernel)
             if gga == 2:                        # kinetic-energy-density term: sum_k ao_k . (w/4 vtau ao_k)^T

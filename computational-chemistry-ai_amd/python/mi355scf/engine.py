@@ -91,6 +91,7 @@ def lib():
         L.mi_xc_eval_mgga_spin.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.mi_xc_vmat.argtypes = [vp, vp, vp, i64, vp, vp]
         L.mi_nystrom_warm.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]
+        L.mi_xc_tail.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
         L.mi_build_fock.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_double, vp, vp, vp]
         L.mi_nystrom_factor.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.mi_sp2_init.argtypes = [vp, vp, vp, vp, vp]
@@ -394,6 +395,13 @@ class Engine:
                                           rhob.data_ptr(), taua.data_ptr(), taub.data_ptr(), weights.data_ptr(), ng, exc.data_ptr(),
                                           wva.data_ptr(), wvb.data_ptr(), self._stream()))
         return exc, wva, wvb
+
+    def xc_tail(self, w, vals, tail):
+        """tail[q] += dot(w, vals[q]) for up to three contiguous vectors, one launch, deterministic."""
+        assert 1 <= len(vals) <= 3 and all(v.is_contiguous() and v.numel() == w.numel() for v in vals) and w.is_contiguous()
+        assert tail.is_contiguous() and tail.numel() >= len(vals)
+        p = [v.data_ptr() for v in vals] + [None] * (3 - len(vals))
+        _check(lib().mi_xc_tail(self._h, w.data_ptr(), p[0], p[1], p[2], w.numel(), tail.data_ptr(), self._stream()))
 
     NYSTROM_MAX_OCC = 64
 

@@ -103,9 +103,7 @@ class UKS(UHF):
                 e, wva, wvb = eng.xc_eval_mgga_spin(terms, rho[0], rho[1], tau[0], tau[1], w)
             else:
                 e, wva, wvb = eng.xc_eval_spin(terms, rho[0], rho[1], w, gga)
-            tail[0] += torch.dot(w, rho[0][0])
-            tail[1] += torch.dot(w, rho[1][0])
-            tail[2] += torch.dot(w, e)
+            eng.xc_tail(w, (rho[0][0], rho[1][0], e), tail)   # N_alpha, N_beta, E_xc of the block: one deterministic launch
             for s_, wv in ((0, wva), (1, wvb)):
                 eng.xc_vmat(ao[0], eng.xc_aow(ao, wv, gga), vmat[s_])
                 if gga == 2:

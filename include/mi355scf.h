@@ -237,6 +237,10 @@ int mi_nystrom_warm(mi_ctx *ctx, const double *d_Zt, const int *d_info, const do
 /* d_Zt[nocc][n] = R^-1 d_W^T with d_M[nocc][nocc] = R R^T (lower Cholesky factor), d_W[n][nocc]; *d_info = 0 or the 1-based index
  * of the first bad pivot (then d_Zt is NaN).  nocc <= 64.  Stands in for torch.linalg.cholesky_ex + solve_triangular. */
 int mi_nystrom_factor(mi_ctx *ctx, const double *d_M, const double *d_W, int n, int nocc, double *d_Zt, int *d_info, void *stream);
+/* d_tail[q] += sum_g d_w[g] d_vq[g] for the non-NULL d_v0..d_v2 (quadrature sums N_elec, E_xc of one grid block), one launch,
+ * fixed summation order.  Stands in for the numpy dots at the end of numint.nr_rks / nr_uks [MEM]. */
+int mi_xc_tail(mi_ctx *ctx, const double *d_w, const double *d_v0, const double *d_v1, const double *d_v2, int64_t ng, double *d_tail,
+               void *stream);
 /* Both steps fused (psi never stored): d_Zp[nao][ldz] = Z with the orbital index fastest, zero-padded to ldz = a multiple of
  * 24 (deriv = 1) or 32 (deriv = 0) columns; d_ao as in mi_xc_rho. */
 int mi_xc_rho_lowrank(mi_ctx *ctx, const double *d_ao, const double *d_Zp, int ldz, int64_t ng, int deriv, double *d_rho,
