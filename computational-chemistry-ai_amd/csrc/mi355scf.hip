@@ -315,6 +315,7 @@ struct mi_ctx {
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
+    int opt_vmat_xcd = 1;    // xc_vmat: XCD-aware workgroup order (tiles of one split share an XCD's L2)
     int opt_vmat_wgs = 0;    // xc_vmat: workgroups aimed at by the split over the grid points (0: 1024 = two per CU; -1: round-1 formula)
     int opt_sp2_persist = 0; // planned purification as ONE resident launch with grid barriers (1: release/acquire fences, 2: write-through
                              // stores + L2-bypassing loads) -- measured SLOWER than one launch per pass (0), see sp2_plan_persist_kernel
@@ -492,6 +493,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_pair") c->opt_jk_pair = (int)value;
     else if (k == "sp2_persist") c->opt_sp2_persist = (int)value;
     else if (k == "vmat_wgs") c->opt_vmat_wgs = (int)value;
+    else if (k == "vmat_xcd") c->opt_vmat_xcd = (int)value;
     else if (k == "tri_tiles") c->opt_tri_tiles = (int)value;       // takes effect at the next mi_eri_prepare
     else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;
     else if (k == "tpq_maxprim") c->opt_tpq_maxprim = value;
@@ -5847,11 +5849,21 @@ extern "C" int mi_commutator_norm(mi_ctx *c, const double *d_M, double *d_E, dou
 #define VM_KS 64
 #define VM_PAD 2 /* see SP2_PAD: conflict-free operand reads for 16 rows x 4 k */
 __global__ __launch_bounds__(256) void xc_vmat_kernel(const double *__restrict__ A, const double *__restrict__ W, int nao, int64_t ng,
-                                                      int64_t kchunk, double *C)
+                                                      int64_t kchunk, double *C, int xcd_order)
 {
     __shared__ double Pa[VM_T][VM_KS + VM_PAD], Pb[VM_T][VM_KS + VM_PAD];
-    const int m0 = blockIdx.y * VM_T, n0 = blockIdx.x * VM_T;
-    const int64_t kbeg = (int64_t)blockIdx.z * kchunk, kend = min(ng, kbeg + kchunk);
+    // 1-D grid of nt^2 x nsplit workgroups.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with an L2
+    // of its own; with the natural order the nt tiles that share a row panel of one split land on different XCDs and every XCD
+    // fetches that panel itself (nt = 5: 2.6 GB through the fabric per pass at N = 264).  XCD-aware order (nsplit a multiple of 8):
+    // workgroup L belongs to XCD L % 8 and works on split (L % 8) + 8 (L / (8 nt^2)), tile (L / 8) % nt^2 -- all tiles of a split
+    // run next to each other on one XCD and share its L2.
+    const int nt = (nao + VM_T - 1) / VM_T, ntt = nt * nt;
+    const int L = (int)blockIdx.x;
+    int tile, split;
+    if (xcd_order) { split = (L & 7) + 8 * (L / (8 * ntt)); tile = (L >> 3) % ntt; }
+    else { tile = L % ntt; split = L / ntt; }
+    const int m0 = (tile / nt) * VM_T, n0 = (tile % nt) * VM_T;
+    const int64_t kbeg = (int64_t)split * kchunk, kend = min(ng, kbeg + kchunk);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qm = (wave >> 1) * 32, qn = (wave & 1) * 32;
     // which of this wave's 2 x 2 blocks of 16 rows / columns lie inside the matrix (wave-uniform)
@@ -5937,7 +5949,15 @@ extern "C" int mi_xc_vmat(mi_ctx *c, const double *d_ao0, const double *d_aow, i
                                           : std::max<int64_t>(1, std::min<int64_t>((ng + 511) / 512, (1024 + nt * nt - 1) / (nt * nt)));
     int64_t kchunk = ((ng + nsplit - 1) / nsplit + VM_KS - 1) / VM_KS * VM_KS;
     nsplit = (ng + kchunk - 1) / kchunk;
-    hipLaunchKernelGGL(xc_vmat_kernel, dim3(nt, nt, (unsigned)nsplit), dim3(256), 0, (hipStream_t)stream, d_ao0, d_aow, c->nao, ng, kchunk, d_vmat);
+    int xcd_order = 0;
+    const int64_t ns8 = nsplit / 8 * 8;       // the XCD-aware order needs a multiple of 8 splits: taken when that costs < 10 % of them
+    if (c->opt_vmat_xcd && ns8 >= 8 && ns8 * 10 >= nsplit * 9) {
+        nsplit = ns8;
+        kchunk = ((ng + nsplit - 1) / nsplit + VM_KS - 1) / VM_KS * VM_KS;
+        xcd_order = 1;
+    }
+    hipLaunchKernelGGL(xc_vmat_kernel, dim3((unsigned)(nt * nt * nsplit)), dim3(256), 0, (hipStream_t)stream, d_ao0, d_aow, c->nao, ng, kchunk,
+                       d_vmat, xcd_order);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -58,6 +58,7 @@ void mi_release_cache(void);
  *   "jk_pipe"     half-tile software pipeline for full-row tiles (-1 auto)
  *   "jk_pair"     n_dm = 2: one pass with two waves per work item (-1 = for stores > 16 GB, 0 = one pass per density, 1 = always)
  *   "grad_dtol"   derivative quartets with q_ab q_cd max|G| below this are skipped (default 1e-13, 0 = Schwarz only)
+ *   "vmat_xcd"    xc_vmat: XCD-aware workgroup order (1, default: the tiles of one split share an XCD's L2; 0: natural order)
  *   "vmat_wgs"    xc_vmat: workgroups aimed at by the split over the grid points (0 = 1024, two full rounds; -1 = round-1 formula)
  *   "sp2_persist" planned purification as ONE resident launch with grid barriers (0 = one launch per pass, default and faster;
  *                 1 = release/acquire fences, 2 = write-through stores + L2-bypassing loads) */

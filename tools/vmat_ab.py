@@ -22,8 +22,8 @@ aow = torch.randn(n, ng, generator=g, dtype=torch.float64, device="cuda")
 ref = None
 for _ in range(30): eng.xc_vmat(ao, aow, torch.zeros(n, n, dtype=torch.float64, device="cuda"))   # clocks
 tile = 0
-for wgs in (-1, 0, 512, 768, 1536, 2048, 4096, -1, 0):
-    eng.set_option("vmat_wgs", wgs)
+for wgs, xcd in ((0, 0), (0, 1), (2048, 0), (2048, 1), (4096, 0), (4096, 1), (0, 0), (0, 1)):
+    eng.set_option("vmat_wgs", wgs); eng.set_option("vmat_xcd", xcd)
     v = torch.zeros(n, n, dtype=torch.float64, device="cuda")
     eng.xc_vmat(ao, aow, v)
     if ref is None: ref = v.clone()
@@ -34,4 +34,4 @@ for wgs in (-1, 0, 512, 768, 1536, 2048, 4096, -1, 0):
     for _ in range(20): eng.xc_vmat(ao, aow, v)
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 20
-    print(json.dumps(dict(case=name, n=n, ng=ng, tile=tile, wgs=wgs, ms=round(ms, 4), tflops=round(2.0 * ng * n * n / ms / 1e9, 1), rel_dev=dev)), flush=True)
+    print(json.dumps(dict(case=name, n=n, ng=ng, xcd=xcd, wgs=wgs, ms=round(ms, 4), tflops=round(2.0 * ng * n * n / ms / 1e9, 1), rel_dev=dev)), flush=True)
