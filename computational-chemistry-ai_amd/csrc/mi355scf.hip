@@ -2314,7 +2314,10 @@ __device__ __forceinline__ d2_t jk_load_chunk(const d2_t *__restrict__ tile, int
 // The compiled tile body is ~1 700 instructions for 384 FMAs: each 16-byte load costs 9 (exec mask for partial blocks, the
 // row stride read back from a spilled SGPR, a 64-bit multiply-add), the rest is AGPR traffic, selects and ds_bpermute of the
 // reduce-scatters.  A specialisation for full 8x8x8x8 tiles (immediate offsets, no masks) let the scheduler hoist all 32 loads,
-// which pushed the kernel to 512 registers and 2.23 ms (from 0.78) -- rejected; any rewrite has to bound the loads in flight.
+// which pushed the kernel to 512 registers and 2.23 ms (from 0.78) -- rejected; scheduling barriers around the tile body did not
+// help (498 registers, 2.19 ms).  For the Coulomb-only build the same specialisation is harmless but its gain (0.742 vs 0.754-0.772
+// ms on one box, 0.770 vs 0.768-0.772 on another; +8 % on the cache-resident cc-pVDZ tensor) is within box-to-box noise: not kept.
+// Any rewrite has to bound the loads in flight by construction.
 template <bool WITH_J, bool WITH_K, bool NT, bool DIJ, bool DKL>
 __device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, const int i, const int k, const int I0, const int J0,
                                                const int K0, const int L0, const int ld, const int bk, const int64_t toff,
