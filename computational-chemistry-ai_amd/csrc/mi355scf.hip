@@ -3442,14 +3442,14 @@ extern "C" int mi_xc_tail(mi_ctx *c, const double *d_w, const double *d_v0, cons
 // Cholesky factor of M = G^T X G [nocc][nocc] (lower, row-major) and the triangular solve Zt = R^-1 W^T in ONE launch (replaces
 // torch.linalg.cholesky_ex + solve_triangular: potf2, reset_info, iota, triu and trsm launches, 48 us per cycle at nocc = 21).
 // W: [n][nocc] row-major; Zt: [nocc][n].  Every workgroup of 64 threads factors M itself in LDS (nocc <= 64: at most 90 k flops)
-// and then solves for its 64 columns, row by row: z_i = (w_i - sum_{j<i} R_ij z_j) / R_ii with the earlier z_j re-read from the
-// output (the thread's own stores).  info[0] = 0, or k + 1 for the first non-positive / non-finite pivot (LAPACK's convention);
+// and then solves for its 64 columns, row by row: z_i = (w_i - sum_{j<i} R_ij z_j) / R_ii with the earlier z_j kept in LDS.  info[0] = 0, or k + 1 for the first non-positive / non-finite pivot (LAPACK's convention);
 // in that case Zt is filled with NaN so that the caller's electron count fails its check.
 #define NYS_MAXOCC 64
 __global__ __launch_bounds__(64) void nystrom_factor_kernel(const double *__restrict__ M, const double *__restrict__ W, int n, int nocc,
                                                             double *Zt, int *__restrict__ info)
 {
     __shared__ double L[NYS_MAXOCC][NYS_MAXOCC + 1];
+    __shared__ double zb[NYS_MAXOCC][64];
     __shared__ int fail_at;
     const int t = threadIdx.x;
     for (int idx = t; idx < nocc * nocc; idx += 64) { const int r = idx / nocc, c = idx - r * nocc; L[r][c] = M[idx]; }
@@ -3478,8 +3478,10 @@ __global__ __launch_bounds__(64) void nystrom_factor_kernel(const double *__rest
     const double *w = W + (size_t)c * nocc;
     for (int i = 0; i < nocc; i++) {
         double z = w[i];
-        for (int j = 0; j < i; j++) z = fma(-L[i][j], Zt[(size_t)j * n + c], z);
-        Zt[(size_t)i * n + c] = failed ? __builtin_nan("") : z / L[i][i];
+        for (int j = 0; j < i; j++) z = fma(-L[i][j], zb[j][t], z);    // this thread's earlier z_j: LDS column t, conflict-free
+        z /= L[i][i];
+        zb[i][t] = z;
+        Zt[(size_t)i * n + c] = failed ? __builtin_nan("") : z;
     }
 }
 
