@@ -2956,85 +2956,79 @@ __device__ __forceinline__ double lane_bcast(double x, int l)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), ls);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// One wave, no LDS, no barriers: lane r owns row r of the augmented system in registers, pivot search and row broadcasts are
-// wave shuffles (the first version -- rows in LDS, lane 0 searching the pivot -- took 14 us, mostly serial LDS latency).
+// One wave, the augmented system [n][n + 1] in LDS, every loop rolled: 5 KB of code.  Lane r owns row r, the pivot is found with a
+// wave reduction, the pivot row is read as LDS broadcasts, back substitution is column oriented.  Three implementations measured
+// the same 14 us per launch (4.8 us of it the floor of any kernel here): rows in LDS with lane 0 scanning for the pivot; a fully
+// unrolled register / v_readlane version (41 KB of code); this one.  What is left is a chain of ~60 dependent LDS / cross-lane
+// round trips on one wave plus two dependent global round trips (partials in, coefficients out).
 __global__ __launch_bounds__(64) void diis_solve_kernel(const double *__restrict__ part, int m, int slot, int space, double *B, double *__restrict__ coef)
 {
+    __shared__ double A[DIIS_MAXM + 1][DIIS_MAXM + 3];   // column n holds the right-hand side
+    __shared__ double X[DIIS_MAXM + 1];
     const int t = threadIdx.x;
     const int n = m + 1;
-    double dot = 0.0;                         // lane i < m: <e_i, e_slot>
-    double bold[DIIS_MAXM];                   // the older Gram entries of this lane's row: requested before anything waits
+    // older Gram entries of this lane's row and the partial sums of the newest row: all requested before anything waits
+    double bold[DIIS_MAXM];
 #pragma unroll
     for (int j = 0; j < DIIS_MAXM; j++) bold[j] = (t >= 1 && t <= m && j < m) ? B[(t - 1) * space + j] : 0.0;
+    double dot = 0.0;                         // lane i < m: <e_i, e_slot>
     if (t < m) {
         double pq[DIIS_NS];
 #pragma unroll
-        for (int q = 0; q < DIIS_NS; q++) pq[q] = part[t * DIIS_NS + q];   // 16 independent loads in flight, then the ordered sum
+        for (int q = 0; q < DIIS_NS; q++) pq[q] = part[t * DIIS_NS + q];
 #pragma unroll
         for (int q = 0; q < DIIS_NS; q++) dot += pq[q];
         B[slot * space + t] = dot;
         B[t * space + slot] = dot;
+        X[t] = dot;                           // staged for the other lanes (row / column `slot` of the system)
     }
-    const double dot_row = __shfl(dot, t > 0 ? t - 1 : 0);   // <e_{r-1}, e_slot> for the lane that owns row r
-    double a[DIIS_MAXM + 1];                  // columns 0..n-1 of row t (compile-time indices only: stays in registers)
-    double rhs = (t == 0) ? 1.0 : 0.0;
+    __syncthreads();
+    if (t < n) {
 #pragma unroll
-    for (int j = 0; j <= DIIS_MAXM; j++) {
-        const double dot_col = __shfl(dot, j > 0 ? j - 1 : 0);
-        double v = 0.0;
-        if (t < n && j < n) {
-            if (t == 0) v = (j == 0) ? 0.0 : 1.0;
-            else if (j == 0) v = 1.0;
-            else if (t - 1 == slot) v = dot_col;
-            else if (j - 1 == slot) v = dot_row;
-            else v = bold[j - 1];                         // older entries: not written by this launch
+        for (int j = 0; j <= DIIS_MAXM; j++) {
+            double v = 0.0;
+            if (j < n) {
+                if (t == 0) v = (j == 0) ? 0.0 : 1.0;
+                else if (j == 0) v = 1.0;
+                else if (t - 1 == slot) v = X[j - 1];
+                else if (j - 1 == slot) v = X[t - 1];
+                else v = bold[j - 1];
+            }
+            A[t][j] = v;
         }
-        a[j] = v;
+        A[t][n] = (t == 0) ? 1.0 : 0.0;
     }
+    __syncthreads();
     bool ok = true;
-#pragma unroll
-    for (int k = 0; k <= DIIS_MAXM; k++) {
-        if (k < n && ok) {
-            // pivot: largest |a[r][k]|, r = k .. n-1 (first one on ties); rows are lanes, so this is a scalar scan of lane reads
-            const double mine = fabs(a[k]);
-            double val = -1.0;
-            int p = k;
-#pragma unroll
-            for (int r = 0; r <= DIIS_MAXM; r++) {
-                if (r >= k && r < n) {
-                    const double v = lane_bcast(mine, r);
-                    if (v > val) { val = v; p = r; }
-                }
-            }
-            if (!(val > 0.0) || !isfinite(val)) ok = false;   // wave-uniform
-            const bool below = t > k && t < n;
-            double f = 0.0;
-#pragma unroll
-            for (int j = 0; j <= DIIS_MAXM; j++) {
-                if (j >= k && j < n) {
-                    const double rk = lane_bcast(a[j], k), rp = lane_bcast(a[j], p);
-                    if (t == k) a[j] = rp; else if (t == p) a[j] = rk;     // rows k and p change places
-                    if (j == k) f = below ? a[k] / rp : 0.0;
-                    if (below) a[j] -= f * rp;                             // (a[k] itself becomes 0)
-                }
-            }
-            const double rk = lane_bcast(rhs, k), rp = lane_bcast(rhs, p);
-            if (t == k) rhs = rp; else if (t == p) rhs = rk;
-            if (below) rhs -= f * rp;
+    for (int k = 0; k < n && ok; k++) {
+        // pivot: largest |A[r][k]|, r = k .. n-1, the first one on ties (LAPACK's idamax)
+        double val = (t >= k && t < n) ? fabs(A[t][k]) : -1.0;
+        int p = t;
+        for (int o = 32; o > 0; o >>= 1) {
+            const double v2 = __shfl_xor(val, o);
+            const int p2 = __shfl_xor(p, o);
+            if (v2 > val || (v2 == val && p2 < p)) { val = v2; p = p2; }
+        }
+        if (!(val > 0.0) || !isfinite(val)) { ok = false; break; }        // wave-uniform
+        if (p != k && t <= n) { const double x = A[k][t]; A[k][t] = A[p][t]; A[p][t] = x; }   // lane t swaps column t
+        __syncthreads();
+        if (t > k && t < n) {
+            const double f = A[t][k] / A[k][k];
+            for (int j = k; j <= n; j++) A[t][j] = fma(-f, A[k][j], A[t][j]);
+        }
+        __syncthreads();
+    }
+    if (ok) {
+        for (int i = n - 1; i >= 0; i--) {
+            if (t == i) X[i] = A[i][n] / A[i][i];
+            __syncthreads();
+            const double xi = X[i];
+            if (!isfinite(xi)) ok = false;                                   // wave-uniform (every lane reads the same value)
+            if (t < i) A[t][n] = fma(-A[t][i], xi, A[t][n]);
+            __syncthreads();
         }
     }
-    double acc = 0.0, myx = 0.0;
-#pragma unroll
-    for (int i = DIIS_MAXM; i >= 0; i--) {
-        if (i < n) {
-            const double cand = (rhs - acc) / a[i];   // meaningful on lane i only
-            const double xi = lane_bcast(cand, i);
-            if (!isfinite(xi)) ok = false;
-            if (t == i) myx = xi;
-            acc += a[i] * xi;
-        }
-    }
-    if (t >= 1 && t <= m) coef[t - 1] = ok ? myx : ((t - 1) == slot ? 1.0 : 0.0);
+    if (t >= 1 && t <= m) coef[t - 1] = ok ? X[t] : ((t - 1) == slot ? 1.0 : 0.0);
 }
 
 extern "C" int mi_diis_solve(mi_ctx *c, const double *d_part, int m, int slot, int space, double *d_B, double *d_coef, void *stream)
