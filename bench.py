@@ -247,7 +247,8 @@ def main():
             dt_ks = time_steps(ks, st_ks, max(10, args.steps // 2), 3, barrier)
             nk = max(10, args.steps // 2)
             secondary = {"workload": f"benzene B3LYP/{args.basis} SCF cycle (BASELINE config 3; level-3 grid, {ks.grids.size} points)",
-                         "value": nk / dt_ks, "unit": "iter/s", "ms_per_step": dt_ks / nk * 1e3, "steps": nk, "e_tot": st_ks["e_tot"]}
+                         "value": nk / dt_ks, "unit": "iter/s", "ms_per_step": dt_ks / nk * 1e3, "steps": nk, "e_tot": st_ks["e_tot"],
+                         "redone_cycles": getattr(ks, "n_redo", 0)}
             if args.basis.lower() != "cc-pvdz":
                 from mi355scf.engine import Engine
                 mol2 = Mole(atom=BENZENE, basis="cc-pVDZ", verbose=0).build()
@@ -267,7 +268,8 @@ def main():
                                       + ("direct mode: tile groups re-evaluated every cycle)" if direct_mode else "resident 8-fold ERI tiles)"),
                           "n_ao": n, "n_unique_eri": stats["n_unique_eri"], "parallelism": f"tile-run shard x{world} (LPT by bytes)",
                           "density_from_fock": args.eig, "object_state": "warm (second and later SCFs of the object; first SCF run in set-up)",
-                          "settle_cycles_before_warmup": SETTLE},
+                          "settle_cycles_before_warmup": SETTLE,
+                          "redone_cycles": getattr(mf, "n_redo", 0)},
                "roofline": roof, "roofline_more": more, "secondary": secondary, "e_tot": st["e_tot"],
                "eri_seconds": stats["seconds_eri"], "setup_seconds": setup_s, "first_scf": first_scf}
         if world == 1 and not args.no_cpu_baseline:

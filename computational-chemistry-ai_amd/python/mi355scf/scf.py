@@ -887,6 +887,7 @@ class SCF:
             # the optimistic purification had not converged (planned path: the spectrum left the planned bounds): roll the DIIS
             # push back and redo this cycle -- planned path by diagonalisation (fresh bounds), otherwise by the checked SP2
             nxt = None
+            self.n_redo = getattr(self, "n_redo", 0) + 1       # diagnostics (bench.py reports it: 0 in a settled loop)
             st["dmo"], st["diis"].count = saved
             st["e_tot"] = e_prev
             self._sp2_validated = False
