@@ -3552,6 +3552,9 @@ __global__ __launch_bounds__(256) void xc_rho_lowrank_kernel(const double *__res
     if (DERIV) { rho[ng + g] = 2 * r1; rho[2 * ng + g] = 2 * r2; rho[3 * ng + g] = 2 * r3; if (tau) tau[g] = 0.5 * tk; }
 }
 
+// n_occ > 24 (ibuprofen: 56 -> three chunks) makes the kernel above walk the AO block once per chunk.  Tried and rejected (round 2,
+// late): one wave per chunk over the same 64 grid points, partial densities added through LDS -- the AO block leaves HBM once, but
+// the ibuprofen RKS cycle went from 27.3-29.5 to 32.9-34.0 ms (64-point workgroups, three waves contending for the same lines).
 extern "C" int mi_xc_rho_lowrank(mi_ctx *c, const double *d_ao, const double *d_Zp, int ldz, int64_t ng, int deriv, double *d_rho,
                                  double *d_tau, void *stream)
 {
