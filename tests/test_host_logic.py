@@ -253,6 +253,27 @@ def test_initial_hessian_models_of_the_optimiser():
     assert steps["lindh"] <= steps["simple"], steps
 
 
+def test_direct_mode_group_plan_cost_model():
+    """`SCF._plan_direct_groups`: (tile groups, resident groups) for an ERI tensor that does not fit the HBM.  C60/6-31G* on one
+    288 GB GPU (500 GB of tiles, 304 GB free): 4 groups with 1 resident beat 3 streamed groups; with less free memory or the
+    Kohn-Sham reserve nothing can stay; the plan never keeps every group and never makes a group larger than what fits."""
+    import numpy as np
+    from mi355scf.scf import RHF
+    from mi355scf.dft import RKS
+
+    def plan(cls, need, free):
+        obj = cls.__new__(cls)                      # the method only reads class attributes
+        return obj._plan_direct_groups(need, free, int(np.ceil(need / (0.8 * free))))
+
+    assert plan(RHF, 500.0, 304.0) == (4, 1)
+    assert plan(RHF, 500.0, 283.0) == (3, 0)
+    assert plan(RKS, 500.0, 304.0)[1] == 0          # 10 GB kept for the quadrature: the second 125 GB store no longer fits
+    for need, free in ((300.0, 280.0), (1000.0, 280.0), (108.0, 60.0), (2000.0, 250.0)):
+        ng, r = plan(RHF, need, free)
+        assert 0 <= r < ng and ng >= int(np.ceil(need / (0.8 * free)))
+        assert (r + 1) * 1.02 * need / ng <= 0.85 * free          # resident groups + the streaming buffer fit
+
+
 def test_thermo_symmetry_numbers_and_diatomic_model():
     """`pyscf.hessian.thermo` host logic: rotational symmetry numbers by brute-force rotation search, harmonic analysis of
     a model diatomic Hessian (omega = sqrt(k/mu)), RRHO identities."""
