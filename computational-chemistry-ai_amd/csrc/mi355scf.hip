@@ -419,6 +419,7 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
 // (one slot per device) and reused by the next context -- e.g. every step of a geometry optimisation.
 struct TileArena { double *ptr = nullptr; int64_t doubles = 0; };
 static TileArena g_arena[16];
+static int64_t g_arena_allocs = 0;
 
 static int arena_take(int dev, int64_t need, double **out)
 {
@@ -429,8 +430,12 @@ static int arena_take(int dev, int64_t need, double **out)
     }
     if (a.ptr) { hipFree(a.ptr); a.ptr = nullptr; a.doubles = 0; }
     HIPCHK(hipMalloc((void **)out, sizeof(double) * need));
+    g_arena_allocs++;
     return 0;
 }
+// Fresh device allocations of tile stores made by this process (a parked store that is reused does not count): a geometry
+// optimisation should show ONE for all its steps.
+extern "C" int64_t mi_tile_store_allocations(void) { return g_arena_allocs; }
 
 static void arena_give(int dev, double *p, int64_t doubles)
 {
@@ -466,6 +471,16 @@ static void free_eri(mi_ctx *c)
     c->d_prim = c->d_M = nullptr; c->d_tile_table = nullptr; c->d_tile_off = nullptr; c->d_tile_I = nullptr;
     c->d_runs = nullptr; c->d_tiles = nullptr; c->d_segs = nullptr; c->d_wave_seg = nullptr;
     c->eri_ready = false;
+}
+
+// Drop the resident tile store and the pair data of the last mi_eri_prepare (the store is parked for reuse, see TileArena).
+// Used when the ranks of a sharded run agree on the direct mode although THIS rank's shard would have fitted.
+extern "C" int mi_eri_release(mi_ctx *c)
+{
+    if (!c) return fail("mi_eri_release: null context");
+    hipSetDevice(c->device);
+    free_eri(c);
+    return 0;
 }
 
 extern "C" void mi_ctx_destroy(mi_ctx *c)

@@ -11,7 +11,7 @@ resident in HBM (8 N^2 N_aux bytes) and every Fock build is a handful of dense F
 
 No JKFIT tables exist offline, so the auxiliary basis is generated: even-tempered exponents per element and angular
 momentum spanning the products of the orbital primitives (the idea of PySCF's `df.aug_etb` [MEM]; not its exact recipe --
-parity with PySCF's fitted energies is UNPINNED), l_aux <= 3 (the engine's kernels stop at f).
+parity with PySCF's fitted energies is UNPINNED), l_aux <= 4 (g auxiliary shells; the two-electron kernels take l <= 4, the Rys tables stop at 8 roots).
 """
 import math
 
@@ -70,7 +70,7 @@ class DF:
         aux = Mole(atom=[(s, xyz) for s, xyz in mol._atom], basis=basis, unit="Bohr", verbose=0, charge=mol.charge, spin=mol.spin)
         aux.build()
         if (aux._bas[:, 1] > LMAX_AUX).any():
-            raise NotImplementedError("auxiliary functions beyond f are not supported")
+            raise NotImplementedError("auxiliary functions beyond g (l > 4) are not supported")
         self.auxmol = aux
         self.naux = aux.nao
         # append the unit function: s primitive, exponent 0, coefficient sqrt(4 pi) (x Y_00 = 1), on atom 0

@@ -194,6 +194,9 @@ class RKS(RHF):
         else:
             R, _info = torch.linalg.cholesky_ex(M)             # no host sync; a failed factorisation shows up as a wrong N_elec
             Zp_t = torch.linalg.solve_triangular(R, W.T, upper=False)   # R^-1 W^T: dmo = Zp Zp^T
+            # `cholesky_ex` returns a finite, partially factored R when it fails: poison the factor so that the cycle's electron
+            # count is NaN and the host sends the cycle through the full-density redo path (the fused kernel NaN-fills itself)
+            Zp_t = Zp_t + torch.where(_info == 0, 0.0, float("nan")).to(Zp_t.dtype)
         # (a cycle whose projector was not valid -- speculative purification, checked later by the host -- must not poison
         # the warm start: keep the Gaussian matrix unless the factor is finite and the factorisation succeeded)
         # ONE launch (`nystrom_warm_kernel`) for what used to be ~14 elementwise / reduction launches per cycle:

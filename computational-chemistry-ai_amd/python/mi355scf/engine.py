@@ -104,6 +104,8 @@ def lib():
         L.mi_grad_eri_spin.argtypes = [vp, vp, vp, ctypes.c_double, vp, vp]
         L.mi_grad_eri_sharded.argtypes = [vp, vp, vp, ctypes.c_double, vp, ctypes.c_int, ctypes.c_int, vp]
         L.mi_eri_get_memory.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        L.mi_eri_release.argtypes = [vp]
+        L.mi_tile_store_allocations.restype = ctypes.c_int64
         L.mi_eri_read_quartet.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
         L.mi_schwarz_get.argtypes = [vp, dp]
         L.mi_df_build.argtypes = [vp, vp, vp, vp, vp]
@@ -126,6 +128,11 @@ def plan_shards(nao, qblk, tol, nranks):
     i64p = ctypes.POINTER(ctypes.c_int64)
     _check(lib().mi_plan_shards(int(nao), _dp(q), float(tol), int(nranks), b.ctypes.data_as(i64p), r.ctypes.data_as(i64p)))
     return b, r
+
+
+def tile_store_allocations():
+    """Fresh device allocations of tile stores made by this process (reuse of a parked store does not count)."""
+    return int(lib().mi_tile_store_allocations())
 
 
 def release_cache():
@@ -221,6 +228,11 @@ class Engine:
         _check(rc)
         self.eri_ready = True
         return self.stats()
+
+    def release_eri(self):
+        """Drop the resident tile store (parked for reuse) and the pair data of the last `prepare_eri`."""
+        _check(lib().mi_eri_release(self._h))
+        self.eri_ready = False
 
     def eri_memory(self):
         """(bytes the last prepare_eri needed, free HBM bytes it saw)."""

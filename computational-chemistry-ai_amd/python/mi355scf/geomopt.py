@@ -226,6 +226,7 @@ def optimize(mf, maxsteps=100, callback=None, coordsys="internal", **kw):
     if res is None:
         res = optimize_cartesian(gs, mol, maxsteps, log, callback)
     mol_opt, converged, step = res
+    mol_opt._opt_converged, mol_opt._opt_steps = bool(converged), int(step)   # (PySCF's wrapper returns only the Mole)
     log("Geometry optimization " + (f"converged in {step} steps" if converged else f"NOT converged in {maxsteps} steps"))
     mol_opt.verbose = mf.mol.verbose
     return mol_opt

@@ -68,6 +68,43 @@ def all_reduce_fused(tensors, group=None):
     return tensors
 
 
+def agree_max(values, group=None):
+    """Element-wise MAX over ranks of a short list of host floats (one small collective; set-up time only).  Used to make
+    rank-local decisions identical on every rank: pass `-x` to agree on a minimum."""
+    vals = [float(v) for v in values]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return vals
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor(vals, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    STATS["agree"] = STATS.get("agree", 0) + 1
+    return [float(v) for v in t.cpu()]
+
+
+_ATOMICS_OFF = False
+
+
+def blas_atomics_off():
+    """Sharded runs keep their replicated algebra (Cholesky transforms, commutators, purification GEMMs) bit-identical across
+    ranks; rocBLAS may pick kernels that accumulate with atomics (run-to-run last-bit differences) unless told not to.
+    Sets `rocblas_atomics_not_allowed` on torch's rocBLAS handle of the current device.  Returns True when it took effect."""
+    global _ATOMICS_OFF
+    if _ATOMICS_OFF:
+        return True
+    try:
+        import ctypes
+        h = torch.cuda.current_blas_handle()
+        # the handle belongs to the rocBLAS torch has loaded (its bundled copy), not to whatever "librocblas.so" resolves to
+        import os
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librocblas.so")
+        rb = ctypes.CDLL(path if os.path.exists(path) else "librocblas.so")
+        rb.rocblas_set_atomics_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _ATOMICS_OFF = rb.rocblas_set_atomics_mode(ctypes.c_void_p(h), 0) == 0   # 0 = rocblas_atomics_not_allowed
+    except Exception:
+        _ATOMICS_OFF = False
+    return _ATOMICS_OFF
+
+
 def split_range(n, rank, nranks):
     """Contiguous, exhaustive, non-overlapping split of range(n)."""
     per = (n + nranks - 1) // nranks

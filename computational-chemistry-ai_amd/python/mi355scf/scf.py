@@ -39,8 +39,14 @@ def _atom_config(z):
 class DeviceDIIS:
     """Pulay CDIIS with the history on the GPU (row a10): e = (SDF)^T - SDF, subspace 8 [MEM defaults]."""
 
+    MAX_SPACE = 16   # DIIS_MAXM of `diis_solve_kernel` (include/mi355scf.h: mi_diis_solve)
+
     def __init__(self, eng, space=8, nmat=1):
         n = eng.nao
+        space = int(space)
+        if not 1 <= space <= self.MAX_SPACE:
+            # (the round-1 host solve took any size; the device solve keeps the Pulay system in one wave's registers)
+            raise ValueError(f"diis_space = {space}: the device-side Pulay solve supports 1..{self.MAX_SPACE} vectors")
         self.eng, self.space, self.count = eng, space, 0
         shape = (space, n, n) if nmat == 1 else (space, nmat, n, n)    # nmat = 2: the spin-stacked pair of UHF / UKS
         self.F = torch.empty(*shape, dtype=torch.float64, device=eng.device)
@@ -147,7 +153,14 @@ class SCF:
     sp2_outer_margin = 2.0    # Hartree the extreme eigenvalues may move outwards
     _sp2_plan = None
     _spin_restricted = True
-    sync_control = False   # sharded runs: broadcast rank 0's control scalars every cycle (not needed: deterministic reductions)
+    # Sharded runs: every rank decides redo / convergence / loop exit from its own replicated algebra.  The own kernels are free
+    # of atomics (fixed-order partial sums) and `parallel.blas_atomics_off()` forbids atomics in rocBLAS, so those scalars are
+    # bit-identical across ranks -- but that rests on library behaviour (rocBLAS kernel selection, rocSOLVER syevd) that no
+    # multi-GPU run has confirmed yet, and a one-ulp difference at a threshold would let one rank leave a loop whose body holds
+    # a collective (a hang).  None = auto: with more than one rank, rank 0's packed control scalars of the cycle (a few KB) are
+    # broadcast once per cycle and every rank decides from that copy; False = no broadcast (zero per-cycle collectives beside
+    # the Fock all-reduce; the world-2 tests assert bit-identical energies in this mode); True = always.
+    sync_control = None
     level_shift = 0.0    # Hartree; virtual-orbital shift applied to the Fock matrix that is diagonalised / purified
 
     def __init__(self, mol):
@@ -209,7 +222,19 @@ class SCF:
         """Shard the resident-ERI tile runs over `nranks` GPUs; J/K partial sums are all-reduced over
         RCCL each Fock build."""
         self._rank, self._nranks, self._pg = rank, nranks, process_group
+        if nranks > 1:
+            from . import parallel
+            parallel.blas_atomics_off()
         return self
+
+    def _sync_control_on(self):
+        """Whether rank 0's control scalars are broadcast every cycle (see `sync_control`)."""
+        if self._nranks <= 1:
+            return False
+        import os
+        if self.sync_control is None:
+            return os.environ.get("MI355_SYNC_CONTROL") != "0"
+        return bool(self.sync_control)
 
     @property
     def engine(self):
@@ -258,14 +283,31 @@ class SCF:
                 self._log(4, f"density fitting: {self.with_df.naux} auxiliary functions, tensor "
                              f"{8e-9 * self.with_df.naux * eng.nao ** 2:.2f} GB, built in {self.timing['df_seconds']:.3f} s")
         elif not eng.eri_ready and self._stream_groups <= 1:
+            oom = False
             try:
                 st = eng.prepare_eri(self.direct_scf_tol, self._rank, self._nranks)
                 self.timing["eri_seconds"] = st["seconds_eri"]
                 self._log(4, f"resident ERI store: {st['n_tiles']} tiles, {st['stored_bytes'] / 1e6:.1f} MB, "
                              f"{st['n_quartets']} shell quartets in {st['seconds_eri']:.3f} s")
+                need, free = eng.eri_memory()
             except _engine.EngineOutOfMemory as e:   # MI_ERR_NOMEM: sizes come through the ABI (mi_eri_get_memory)
-                need, free = e.need_bytes * 1e-9, e.free_bytes * 1e-9
-                self._stream_groups = int(np.ceil(need / max(0.8 * free, 1.0)))
+                oom, need, free = True, e.need_bytes, e.free_bytes
+            view = getattr(self, "_test_memory_view", None)
+            if view is not None:    # tests: pretend this rank saw (oom, need_bytes, free_bytes)
+                oom, need, free = view
+            if self._nranks > 1:
+                # The direct-mode split is (rank * ng + v, nranks * ng) over ONE flat LPT deal of the tile runs, so every rank
+                # must use the same ng (and the same number of resident groups): with rank-local values the tile sets of two
+                # ranks would be neither disjoint nor exhaustive.  One MAX all-reduce at set-up: direct mode if ANY rank's
+                # shard does not fit, sized for the largest shard and the smallest free HBM.
+                from . import parallel
+                o, n_, f_ = parallel.agree_max([1.0 if oom else 0.0, float(need), -float(free)], self._pg)
+                oom, need, free = o > 0.0, n_, -f_
+            if oom:
+                if eng.eri_ready:
+                    eng.release_eri()       # this rank's shard fitted, another rank's did not: everybody goes direct
+                need, free = need * 1e-9, free * 1e-9
+                self._stream_groups = max(2, int(np.ceil(need / max(0.8 * free, 1.0))))
                 if self.direct_resident:
                     self._stream_groups, self._resident_groups = self._plan_direct_groups(need, free, self._stream_groups)
                 self._log(3, f"ERI tensor shard ({need:.0f} GB) exceeds free HBM ({free:.0f} GB): direct mode, "
@@ -323,23 +365,40 @@ class SCF:
 
         ge = self._group_engines
         nres = min(int(getattr(self, "_resident_groups", 0) or 0), ng - 1)
+        gstats = self.__dict__.setdefault("_group_stats", {})
         while len(ge) < nres:
             v = len(ge)
             g = _engine.Engine(self.mol, device=eng.device)
+            ok = True
             try:
-                g.prepare_eri(self.direct_scf_tol, self._rank * ng + v, self._nranks * ng)
+                gstats[v] = g.prepare_eri(self.direct_scf_tol, self._rank * ng + v, self._nranks * ng)
             except _engine.EngineOutOfMemory:
+                ok = False
+            if ok:
+                free, _tot = torch.cuda.mem_get_info(eng.device)
+                more = free >= 2.3 * g.stats()["stored_bytes"] + self.direct_reserve_gb * 2 ** 30
+            else:
+                more = False
+            if self._nranks > 1:
+                # which groups stay resident decides which (rank * ng + v) shares are streamed by eng below: the group INDEX
+                # sets must match on all ranks (each group index is a different share of every rank's runs), so a rank-local
+                # failure or memory shortage ends the resident prefix everywhere
+                from . import parallel
+                bad, stop = parallel.agree_max([0.0 if ok else 1.0, 0.0 if more else 1.0], self._pg)
+                if bad > 0.0 and ok:
+                    gstats.pop(v, None)
+                ok, more = bad == 0.0, stop == 0.0
+            if not ok:
                 g.close()
                 nres = self._resident_groups = len(ge)
                 break
             ge.append(g)
-            free, _tot = torch.cuda.mem_get_info(eng.device)
-            if free < 2.3 * g.stats()["stored_bytes"] + self.direct_reserve_gb * 2 ** 30:
+            if not more:
                 nres = self._resident_groups = len(ge)   # no room for one more AND the streaming buffer of the other groups
         for g in ge[:nres]:
             add(*g.get_jk(dm, with_j, with_k))
         for v in range(nres, ng):
-            eng.prepare_eri(self.direct_scf_tol, self._rank * ng + v, self._nranks * ng)
+            gstats[v] = eng.prepare_eri(self.direct_scf_tol, self._rank * ng + v, self._nranks * ng)
             add(*eng.get_jk(dm, with_j, with_k))
         return J, K   # pair records / Schwarz data of the last group stay valid (used by the gradient)
 
@@ -527,6 +586,7 @@ class SCF:
         torch.matmul(X, X, out=X2)
         return X + X.T, torch.stack([torch.trace(X), torch.trace(X2)])   # exactly symmetric 2 X (see _sp2_planned_gemm)
 
+    xc_nelec_rtol = 2e-4   # relative error of the grid electron count a low-rank-factor cycle may show (level-3 grids: ~1e-5)
     _HEAD_MAX = 4096   # doubles reserved in front of the planned-path trace history for [E partials | |g|^2 partials | extra]
 
     def _sp2_planned_async(self, fo, nocc, scale=2.0):
@@ -653,8 +713,11 @@ class SCF:
         mol = self.mol
         self._setup_once()
         eng = self.engine
+        t0 = time.time()
         if dm0 is None:
             dm0 = self.get_init_guess()
+        self.timing["guess_seconds"] = time.time() - t0
+        t0 = time.time()
         dm = torch.as_tensor(np.asarray(dm0), dtype=torch.float64, device=eng.device).contiguous()
         if self._nranks > 1:   # one-off: identical starting density on every rank (the atomic guess is built with atomics per rank)
             from . import parallel
@@ -662,6 +725,7 @@ class SCF:
         st = {"nocc": mol.nelectron // 2, "enuc": mol.energy_nuc(), "cycle": 0, "diis": DeviceDIIS(eng, self.diis_space)}
         st["dmo"] = self._L.T @ dm @ self._L
         self._after_density(st, dm, e_last=None, next_cycle=0)
+        self.timing["first_fock_seconds"] = time.time() - t0
         return st
 
     def _after_density(self, st, dm, e_last, next_cycle, sp2_tr=None, nocc=0, hist_shape=None):
@@ -715,9 +779,9 @@ class SCF:
             parts = [part] + ([extra.reshape(-1)] if extra is not None else []) + ([sp2_tr] if sp2_tr is not None else [])
             packed = torch.cat(parts) if len(parts) > 1 else part
         # Sharded runs: every rank holds the same all-reduced J/K(/Vxc) and the replicated algebra above is free of atomics
-        # (fixed-order partial sums), so these scalars are bit-identical on all ranks and steer identical control flow --
-        # no broadcast.  `sync_control = True` restores the round-1 broadcast of rank 0's copy (debugging aid).
-        if self._nranks > 1 and self.sync_control:
+        # (fixed-order partial sums), so these scalars should be bit-identical on all ranks; until a multi-GPU run has confirmed
+        # that for the library GEMMs in between, rank 0's copy is made authoritative (`sync_control`, one small broadcast).
+        if self._sync_control_on():
             from . import parallel
             parallel.broadcast0(packed, self._pg)
         ctx = dict(dm=dm, fock=fock, fo=fo, nb=nb, n_extra=0 if extra is None else extra.numel(), has_tr=sp2_tr is not None,
@@ -753,7 +817,7 @@ class SCF:
                 # (dft.RKS._occ_factor): a failed factorisation (NaN, or a count off by more than the grid error) sends the
                 # cycle through the redo path, which uses the full density matrix
                 nel = float(vals[pos])
-                if not (abs(nel - 2.0 * st["nocc"]) < 0.01 * 2.0 * st["nocc"]):
+                if not (abs(nel - 2.0 * st["nocc"]) < self.xc_nelec_rtol * 2.0 * st["nocc"]):
                     return False
             e_el += float(vals[pos + ne - 1])
             pos += ne
@@ -927,6 +991,7 @@ class SCF:
         st.pop("front", None)                            # the speculative head of a cycle that will not run
         self.cycles = st["cycle"]
         self.timing["loop_seconds"] = time.time() - t_loop
+        t_final = time.time()
         if self.converged and self.conv_check:
             self._step(st, use_diis=False, want_mo=True)
             self._log(4, f"Extra cycle  E= {st['e_tot']:.15g}  delta_E= {st['de']:.3g}")
@@ -942,6 +1007,7 @@ class SCF:
         occ = np.zeros(eng.nao)
         occ[:st["nocc"]] = 2.0
         self.mo_occ = occ
+        self.timing["final_seconds"] = time.time() - t_final
         self.timing["total_seconds"] = time.time() - t_start
         if self.converged:
             self._log(3, f"converged SCF energy = {self.e_tot:.15g}")

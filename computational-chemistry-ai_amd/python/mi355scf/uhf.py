@@ -145,7 +145,7 @@ class UHF(SCF):
         small = n < self.sp2_min_nao or self.eig_method != "sp2"
         warm = all(no == 0 or sp.vals["_sp2_plan"] is not None for sp, no in zip(self._spin_states(n), (na, nb)))
         use_fast = self.fast_loop and (small or (self.fast_loop == "always" and warm))
-        if use_fast and not (self._nranks > 1 and self.sync_control):
+        if use_fast and not self._sync_control_on():
             return self._kernel_fast(dm0)
         return self._kernel_plain(dm0)
 
@@ -440,9 +440,9 @@ class UHF(SCF):
         conv_tol_grad = self.conv_tol_grad if self.conv_tol_grad is not None else np.sqrt(conv_tol)
         # sharded runs: the all-reduced J/K(/Vxc) are identical on every rank and the replicated algebra below is made of
         # deterministic library reductions, so the ranks stay bit-identical without broadcasting control scalars;
-        # `sync_control = True` restores the round-1 broadcast of rank 0's Gram row / scalars (debugging aid)
+        # `sync_control` (auto-on for sharded runs, see scf.SCF) makes rank 0's Gram row / scalars authoritative
         sync = None
-        if self._nranks > 1 and self.sync_control:
+        if self._sync_control_on():
             from . import parallel
             sync = lambda t: parallel.broadcast0(t, self._pg)
         diis = PairDIIS(self.diis_space, sync)

@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def free_port():
+    """A TCP port the kernel just handed out (for torch.distributed rendezvous on 127.0.0.1)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 MOLECULES = {
     "h2o": "O 0 0 0; H 0 -0.757 0.587; H 0 0.757 0.587",
     "h2co": "C 0 0 0; O 1.2 0 0; H -0.5 0.9 0; H -0.5 -0.9 0",  # reference README.md:187-192

@@ -7,21 +7,21 @@ import sys
 import pytest
 import torch.multiprocessing as mp
 
-from conftest import ROOT, MOLECULES
+from conftest import ROOT, MOLECULES, free_port
 
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, method, q):
+def _worker(rank, world, port, method, q, opts=None):
     try:
-        _worker_body(rank, world, port, method, q)
+        _worker_body(rank, world, port, method, q, opts or {})
     except BaseException as e:   # never leave the parent waiting on the queue
         import traceback
         q.put((rank, "error", traceback.format_exc()))
         raise
 
 
-def _worker_body(rank, world, port, method, q):
+def _worker_body(rank, world, port, method, q, opts):
     sys.path.insert(0, os.path.join(ROOT, "computational-chemistry-ai_amd", "python"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -41,18 +41,31 @@ def _worker_body(rank, world, port, method, q):
         mf.xc = method.lstrip("U")
     mf.conv_tol = 1e-10
     mf.shard(rank, world)
+    if "sync_control" in opts:
+        mf.sync_control = opts["sync_control"]
+    if "memory_views" in opts:      # (oom, need_bytes, free_bytes) this rank pretends to have seen in mi_eri_prepare
+        mf._test_memory_view = opts["memory_views"][rank]
+        mf.direct_reserve_gb = 0.0
     parallel.reset_stats()
     e = mf.kernel()
-    coll = dict(parallel.STATS, fock_builds=mf.n_fock_builds)   # initial build + one per cycle (+ redone ones) + the extra cycle
+    coll = dict(parallel.STATS, fock_builds=mf.n_fock_builds, sync=mf._sync_control_on(),   # initial build + one per cycle (+ redone) + extra cycle
+                groups=(mf._stream_groups, mf._resident_groups))
     st = mf.engine.stats()
+    if mf._stream_groups > 1:       # direct mode: tiles / unique integrals of ALL groups this rank evaluated
+        gs = mf._group_stats
+        assert sorted(gs) == list(range(mf._stream_groups)), sorted(gs)
+        st = {k: sum(g[k] for g in gs.values()) for k in ("n_tiles", "n_unique_eri")}
     g = mf.nuc_grad_method().kernel()
     q.put((rank, e, bool(mf.converged), st["n_tiles"], st["n_unique_eri"], g.tolist(), coll, float(e).hex()))
     import torch.distributed as dist
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("method", ["HF", "B3LYP", "UHF", "UB3LYP"])
+@pytest.mark.parametrize("method", ["HF", "B3LYP", "UHF", "UB3LYP", "HF-nosync", "B3LYP-nosync"])
 def test_two_rank_sharded_scf_matches_single(method):
+    opts = {}
+    if method.endswith("-nosync"):      # zero per-cycle broadcasts: the ranks must stay bit-identical on their own
+        method, opts = method[:-7], {"sync_control": False}
     from pyscf import gto, scf, dft
     mol = gto.Mole()
     mol.atom = MOLECULES["h2co"]
@@ -70,8 +83,8 @@ def test_two_rank_sharded_scf_matches_single(method):
     g1 = mf.nuc_grad_method().kernel()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + (os.getpid() % 90) + 100 * ["HF", "B3LYP", "UHF", "UB3LYP"].index(method)   # one rendezvous port per case
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, method, q)) for r in range(2)]
+    port = free_port()   # a port the kernel just handed out: no collisions between suites sharing a host
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, method, q, opts)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in procs)
@@ -90,10 +103,104 @@ def test_two_rank_sharded_scf_matches_single(method):
     # SURVEY.md section 8e / VERDICT r1 item 6: exactly ONE collective per Fock build ([J|K] or the fused [J|K|Vxc|N|Exc]
     # buffer) and NO broadcast inside the SCF loop (two one-off broadcasts at set-up make the inputs identical) -- the
     # replicated algebra is deterministic, so the ranks' energies are bit-identical without exchanging control scalars
+    # Round 3: by default rank 0's packed control scalars are ALSO broadcast once per Fock build (`sync_control`
+    # auto-on) until a multi-GPU run has confirmed the bit-identity; the "-nosync" cases keep the zero-broadcast mode covered.
     for r in res:
-        assert r[6]["broadcast"] == 2, r[6]       # set-up only: [S|h] and the starting density, whatever the number of cycles
+        assert r[6]["sync"] == ("sync_control" not in opts)
+        nb = r[6]["fock_builds"] if (r[6]["sync"] and not method.startswith("U")) else 0
+        if r[6]["sync"] and method.startswith("U"):
+            assert r[6]["broadcast"] > 2, r[6]    # plain UHF/UKS loop: Gram row + control scalars per cycle
+        else:
+            assert r[6]["broadcast"] == 2 + nb, r[6]   # set-up: [S|h] and the starting density, whatever the number of cycles
         assert r[6]["all_reduce"] == r[6]["fock_builds"], r[6]
     assert res[0][7] == res[1][7], (res[0][7], res[1][7])
+
+
+def test_two_ranks_with_different_memory_views_agree_on_the_direct_mode_split():
+    """the direct-mode group count used to come from each rank's own free HBM; two ranks picking different counts
+    deal (rank * ng + v, nranks * ng) over different plans -> tile sets neither disjoint nor exhaustive, J/K silently wrong.
+    Rank 0 pretends its shard did not fit (1 GB needed, 0.45 GB free), rank 1 that everything fitted (0.2 GB / 200 GB): after
+    the set-up MAX all-reduce both use the same (groups, resident); the union of the groups' tiles is the whole tensor and
+    the energy equals the unsharded one."""
+    from pyscf import gto, scf
+    mol = gto.Mole()
+    mol.atom = MOLECULES["h2co"]
+    mol.basis = "6-31G(d)"
+    mol.verbose = 0
+    mol.build()
+    mf = scf.RHF(mol)
+    mf.conv_tol = 1e-10
+    e1 = mf.kernel()
+    st1 = mf.engine.stats()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    opts = {"memory_views": [(True, 1.0e9, 0.45e9), (False, 0.2e9, 200e9)]}
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, "HF", q, opts)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert not any(r[1] == "error" for r in res), [r[2] for r in res if r[1] == "error"]
+    assert res[0][6]["groups"] == res[1][6]["groups"] and res[0][6]["groups"][0] >= 2, (res[0][6], res[1][6])
+    assert res[0][3] + res[1][3] == st1["n_tiles"] and res[0][4] + res[1][4] == st1["n_unique_eri"]
+    assert all(r[2] for r in res) and abs(res[0][1] - e1) < 5e-9 and res[0][7] == res[1][7]
+
+
+def test_rccl_world1_allreduce_of_the_fused_fock_buffer():
+    """The only RCCL exercise one GPU allows: initialise the `nccl` backend (= RCCL on ROCm) with world_size 1 in a child
+    process and push the fused [J|K|Vxc|N|Exc] buffer of a Kohn-Sham Fock build through `dist.all_reduce` -- the code path
+    (`parallel.init("nccl")`, device-resident FP64 buffer, SUM) the 8-GPU runs use."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(free_port(), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    if p.is_alive():
+        p.kill()
+    assert res[0] == "ok", res
+
+
+def _rccl_worker(port, q):
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "computational-chemistry-ai_amd", "python"))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        import torch
+        import torch.distributed as dist
+        from mi355scf import parallel
+        from pyscf import gto, dft
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        assert dist.get_backend() == "nccl"
+        mol = gto.Mole()
+        mol.atom = MOLECULES["h2co"]
+        mol.basis = "6-31G(d)"
+        mol.verbose = 0
+        mol.build()
+        ks = dft.RKS(mol)
+        ks.xc = "B3LYP"
+        e = ks.kernel()
+        n = mol.nao
+        buf = torch.randn(3 * n * n + 2, dtype=torch.float64, device="cuda")     # [J|K|Vxc|N|Exc]
+        ref = buf.clone()
+        dist.all_reduce(buf)                                    # world 1: must return the input, through RCCL
+        torch.cuda.synchronize()
+        same = bool(torch.equal(buf, ref))
+        t = torch.tensor([1.0, 2.0, -3.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.broadcast(buf, src=0)
+        ok_atomics = parallel.blas_atomics_off()               # rocBLAS handle reachable: atomics forbidden for sharded runs
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(("ok" if (same and ks.converged and t.tolist() == [1.0, 2.0, -3.0] and ok_atomics) else "bad", same, float(e), ok_atomics))
+    except BaseException:
+        import traceback
+        q.put(("error", traceback.format_exc()))
+        raise
 
 
 def test_direct_mode_streamed_tile_groups_match_resident():

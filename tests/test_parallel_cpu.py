@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.multiprocessing as mp
 
-from conftest import ROOT, MOLECULES
+from conftest import ROOT, MOLECULES, free_port
 
 
 def _worker(rank, world, port, q):
@@ -64,7 +64,7 @@ def _worker(rank, world, port, q):
 def test_fused_allreduce_of_partial_jk_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400)
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
