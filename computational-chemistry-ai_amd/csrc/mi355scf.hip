@@ -178,7 +178,8 @@ extern "C" int mi_rys_roots_host(int n, double x, double *roots, double *weights
 // Context
 // =================================================================================================
 struct ShellH {
-    int atom, l, nprim, ao;
+    int atom, l, nprim, ao;   // ao: first AO in the TILE order of the ERI store (see set_tile_order); ao_nat: in the caller's order
+    int ao_nat;
     const double *exps, *coef;
     double r[3];
 };
@@ -199,11 +200,13 @@ struct PairClass {
     int nsab;                      // (2la+1)(2lb+1)
     std::vector<PairRec> recs;     // sorted by q desc after Schwarz
     std::vector<double> q;         // Schwarz bound per rec
+    std::vector<double> cq;        // non-increasing along the sorted list: max q over the rec's cluster (== q without clustering)
     PairRec *d_recs = nullptr;
     double *d_q = nullptr;
     // primitive-pair counts of the sorted list: mean, and mean over windows of 4 consecutive pairs of the window maximum
     // (four consecutive tasks share a wave in the 16-lane-group kernels and run as long as the longest of them)
     double mean_np = 1.0, max4_np = 1.0;
+    int max_np = 1;                // largest primitive-pair count of a pair of the class
 };
 
 struct TileInfo { int I, J, K, L; };
@@ -315,6 +318,14 @@ struct mi_ctx {
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
+    int opt_ao_order = 1;    // tile AO order: 1 = angular-momentum major (all s, all p, ... ; tiles become class-homogeneous), 0 = caller's
+    int opt_ket_cluster = 1; // kets ordered by (block pair of the store, shell) inside Schwarz-ordered clusters instead of by q alone
+    int opt_xf_mlds = 0;     // transform kernel: stage the per-pair matrices in LDS when a quartet's blocks then fit this many KB (0: never; measured 1.3-3x SLOWER at 16-96)
+    int opt_prim_lds = 0;    // Rys kernel: primitive-pair records of the quartet staged in LDS
+    int opt_xcd_map = 1;     // ERI kernels: consecutive task chunks stay on one XCD (its L2 merges the pieces of a line)
+    int ao_order = 0;        // order of the current shells[].ao / d_perm
+    int *d_perm = nullptr, *d_iperm = nullptr;   // caller AO -> tile AO and back
+    std::vector<int> perm, iperm;
     int opt_vmat_xcd = 1;    // xc_vmat: XCD-aware workgroup order (tiles of one split share an XCD's L2)
     int opt_vmat_wgs = 0;    // xc_vmat: workgroups aimed at by the split over the grid points (0: 1024 = two per CU; -1: round-1 formula)
     int opt_sp2_persist = 0; // planned purification as ONE resident launch with grid barriers (1: release/acquire fences, 2: write-through
@@ -329,6 +340,34 @@ static inline int pc_index(int la, int lb) { return la * (la + 1) / 2 + lb; }
 static inline int ne_of(int la, int lb) { int n = 0; for (int e = la; e <= la + lb; e++) n += ncart(e); return n; }
 
 static double gaussian_int(int n, double a) { return std::tgamma((n + 1) * 0.5) / (2.0 * std::pow(a, (n + 1) * 0.5)); }
+
+// AO order of the ERI store ("tile order").  order 0: the caller's (shell by shell as in `bas`).  order 1: angular-momentum
+// major -- all s shells, then all p, d, f (shells of one l in the caller's sequence) -- so that an 8-AO block holds shells of
+// ONE l (but for three boundary blocks): every tile then belongs to one angular class, and the pieces of a 64-byte line of the
+// store (4 consecutive k x one l pair) come from quartets of the SAME class, i.e. of one launch, which lets neighbouring
+// lanes / workgroups complete the line together.  The permutation is internal: densities are gathered into
+// tile order when they are padded, J / K / F are scattered back by the finalize kernels.
+static int set_tile_order(mi_ctx *c, int order)
+{
+    if (c->ao_order == order) return 0;
+    const int nbas = c->nbas;
+    std::vector<int> seq(nbas);
+    std::iota(seq.begin(), seq.end(), 0);
+    if (order == 1) std::stable_sort(seq.begin(), seq.end(), [&](int a, int b) { return c->shells[a].l < c->shells[b].l; });
+    c->perm.assign(std::max(c->nao, 1), 0);
+    c->iperm.assign(std::max(c->nao, 1), 0);
+    int pos = 0;
+    for (int s_ : seq) {
+        ShellH &S = c->shells[s_];
+        S.ao = pos;
+        for (int m = 0; m < 2 * S.l + 1; m++) { c->perm[S.ao_nat + m] = pos + m; c->iperm[pos + m] = S.ao_nat + m; }
+        pos += 2 * S.l + 1;
+    }
+    HIPCHK(hipMemcpy(c->d_perm, c->perm.data(), sizeof(int) * c->perm.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_iperm, c->iperm.data(), sizeof(int) * c->iperm.size(), hipMemcpyHostToDevice));
+    c->ao_order = order;
+    return 0;
+}
 
 extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, int nbas, const double *env,
                              int nenv, int device_id, mi_ctx **out)
@@ -352,7 +391,7 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
         if (b[3] != 1) { delete c; return fail("shell %d: nctr=%d unsupported (split general contractions)", i, b[3]); }
         if (b[1] < 0 || b[1] > LMAX) { delete c; return fail("shell %d: l=%d unsupported (max %d)", i, b[1], LMAX); }
         ShellH s;
-        s.atom = b[0]; s.l = b[1]; s.nprim = b[2]; s.ao = ao;
+        s.atom = b[0]; s.l = b[1]; s.nprim = b[2]; s.ao = ao; s.ao_nat = ao;
         s.exps = c->env.data() + b[5]; s.coef = c->env.data() + b[6];
         const double *r = c->env.data() + atm[(size_t)s.atom * ATM_SLOTS + 1];
         s.r[0] = r[0]; s.r[1] = r[1]; s.r[2] = r[2];
@@ -411,6 +450,10 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
     HIPCHK(hipMalloc(&c->d_Jacc, sizeof(double) * 2 * pp));
     HIPCHK(hipMalloc(&c->d_Kacc, sizeof(double) * 2 * pp));
     HIPCHK(hipMalloc(&c->d_red, sizeof(double) * 4096));
+    HIPCHK(hipMalloc(&c->d_perm, sizeof(int) * std::max(ao, 1)));
+    HIPCHK(hipMalloc(&c->d_iperm, sizeof(int) * std::max(ao, 1)));
+    c->ao_order = -1;
+    if (set_tile_order(c, 0)) { return -1; }
     *out = c;
     return 0;
 }
@@ -419,7 +462,7 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
 // (one slot per device) and reused by the next context -- e.g. every step of a geometry optimisation.
 struct TileArena { double *ptr = nullptr; int64_t doubles = 0; };
 static TileArena g_arena[16];
-static int64_t g_arena_allocs = 0;
+static std::vector<int64_t> g_arena_alloc_bytes;   // size of every fresh tile-store allocation of this process
 
 static int arena_take(int dev, int64_t need, double **out)
 {
@@ -430,12 +473,17 @@ static int arena_take(int dev, int64_t need, double **out)
     }
     if (a.ptr) { hipFree(a.ptr); a.ptr = nullptr; a.doubles = 0; }
     HIPCHK(hipMalloc((void **)out, sizeof(double) * need));
-    g_arena_allocs++;
+    g_arena_alloc_bytes.push_back((int64_t)sizeof(double) * need);
     return 0;
 }
-// Fresh device allocations of tile stores made by this process (a parked store that is reused does not count): a geometry
-// optimisation should show ONE for all its steps.
-extern "C" int64_t mi_tile_store_allocations(void) { return g_arena_allocs; }
+// Fresh device allocations of tile stores of at least `min_bytes` made by this process (a parked store that is reused does
+// not count): a geometry optimisation should show ONE large one for all its steps (the atomic-guess engines make tiny ones).
+extern "C" int64_t mi_tile_store_allocations(int64_t min_bytes)
+{
+    int64_t n = 0;
+    for (int64_t b : g_arena_alloc_bytes) n += b >= min_bytes;
+    return n;
+}
 
 static void arena_give(int dev, double *p, int64_t doubles)
 {
@@ -489,7 +537,7 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     hipSetDevice(c->device);
     free_eri(c);
     void *ptrs[] = {c->d_env, c->d_bas, c->d_atm, c->d_shell_ao, c->d_c2s, c->d_rys_cheb, c->d_herm_r, c->d_herm_w,
-                    c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red, c->d_shell_xyz, c->d_sp2_bar, c->d_xt_scratch};
+                    c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red, c->d_shell_xyz, c->d_sp2_bar, c->d_xt_scratch, c->d_perm, c->d_iperm};
     for (void *p : ptrs) if (p) hipFree(p);
     delete c;
 }
@@ -510,6 +558,11 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "vmat_wgs") c->opt_vmat_wgs = (int)value;
     else if (k == "vmat_xcd") c->opt_vmat_xcd = (int)value;
     else if (k == "tri_tiles") c->opt_tri_tiles = (int)value;       // takes effect at the next mi_eri_prepare
+    else if (k == "ao_order") c->opt_ao_order = (int)value;         // takes effect at the next mi_eri_prepare
+    else if (k == "ket_cluster") c->opt_ket_cluster = (int)value;   // takes effect at the next mi_eri_prepare
+    else if (k == "xcd_map") c->opt_xcd_map = (int)value;
+    else if (k == "prim_lds") c->opt_prim_lds = (int)value;
+    else if (k == "xf_mlds") c->opt_xf_mlds = (int)value;
     else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;
     else if (k == "tpq_maxprim") c->opt_tpq_maxprim = value;
     else if (k == "xf_mfma_min") c->opt_xf_mfma_min = (int)value;   // takes effect at the next mi_eri_prepare
@@ -729,7 +782,27 @@ struct EriArgs {
     double dtol, hyb;
     // host side only (kernel choice): primitive-pair statistics of the shared (bra) and the varying (ket) pair list
     double h_shared_np, h_vary_mean, h_vary_max4;
+    int prim_lds;            // > 0: stage the primitive-pair records of the quartet in LDS (room for this many records per quartet)
+    double qtol;             // > 0: skip tasks with q_bra q_ket < qtol (kets of a surviving cluster that fail the Schwarz test themselves)
+    unsigned xcd;            // > 0: XCD-aware block map with chunks of this many blocks (xcd_block), grid rounded up to 8 * xcd
 };
+
+// Block index -> position in the task order such that `C` consecutive positions run on ONE XCD (blocks b and b + 8 share an
+// XCD under the observed round-robin placement; speed only, never correctness): the pieces of a tile line written by
+// neighbouring tasks then meet in one L2.  Chunks alternate over the XCDs, so the load stays balanced along the task list.
+// The grid must be a multiple of 8 C (eri_grid); positions beyond the task count idle.
+__device__ inline unsigned xcd_block(unsigned b, unsigned C)
+{
+    if (C == 0u) return b;
+    const unsigned x = b & 7u, r = b >> 3;
+    return ((r / C) * 8u + x) * C + (r % C);
+}
+static inline unsigned eri_grid(int64_t nblocks, unsigned C)
+{
+    if (C == 0u) return (unsigned)nblocks;
+    const int64_t m = 8 * (int64_t)C;
+    return (unsigned)((nblocks + m - 1) / m * m);
+}
 
 // Upper bound of |G| = |D_ab D_cd - hyb/4 (D_ac D_bd + D_ad D_bc)| over the AO quadruples of a shell quartet.
 __device__ inline double quartet_density_bound(const double *dmax, int nb, int a, int b, int c, int d, double hyb)
@@ -786,7 +859,8 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
     extern __shared__ double lds_all[];
     constexpr int QPW = 64 / GSZ;
     const int grp = QPW == 1 ? 0 : threadIdx.x / GSZ, lane = QPW == 1 ? threadIdx.x : threadIdx.x % GSZ;
-    const int tl = blockIdx.x * QPW + grp; // task inside this launch
+    const int tl = (int)xcd_block(blockIdx.x, A.xcd) * QPW + grp; // task inside this launch
+    if (QPW == 1 && tl >= A.ntask) return;   // (grid rounded up for the XCD map)
     bool live = QPW == 1 || tl < A.ntask;
     const int64_t task = A.t0 + (live ? tl : 0);
     int ib, ik;
@@ -794,6 +868,7 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
     else find_task(A.prefix, A.nbra, task, ib, ik);
     if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
+    if (A.qtol > 0.0 && A.q_bra[ib] * A.q_ket[ik] < A.qtol) { if (QPW == 1) return; live = false; }
     if (QPW == 1) { // one quartet per wave: negligible / non-resident quartets leave at once
         if (A.own_table && !quartet_has_resident_tile(A.own_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane)) return;
         if (A.dmax && A.q_bra[ib] * A.q_ket[ik] * quartet_density_bound(A.dmax, A.nbas_d, ab.sh_i, ab.sh_j, cd.sh_i, cd.sh_j, A.hyb) < A.dtol) return;
@@ -805,9 +880,23 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
     const int n = A.nroots, tsz = A.tsz, M1 = A.mmax + 1;
     const int ncd = cd.nprim, nPQ = live ? ab.nprim * ncd : 0;
     const int PB = A.PB;
-    double *lds = QPW == 1 ? lds_all : lds_all + (size_t)grp * ((size_t)PB * n * 3 * tsz + (size_t)PB * 2 * n);
+    const size_t lds_per = (size_t)PB * n * 3 * tsz + (size_t)PB * 2 * n + (size_t)A.prim_lds * 8;
+    double *lds = QPW == 1 ? lds_all : lds_all + (size_t)grp * lds_per;
     double *T0 = lds;                       // [PB*n][3][tsz]
     double *rw = lds + (size_t)PB * n * 3 * tsz; // [PB][2n]
+    // primitive-pair records {p, P, P-A, K} of the bra and the ket pair: staged once per quartet in LDS (coalesced 64-byte
+    // records) so that the R and A phases of every batch read them on-chip instead of paying a global round trip each
+    const double *prim_b = A.prim + (size_t)ab.prim_off * 8, *prim_k = A.prim + (size_t)cd.prim_off * 8;
+    if (A.prim_lds > 0) {
+        double *pl = rw + (size_t)PB * 2 * n;
+        const int nb8 = ab.nprim * 8, nk8 = ncd * 8;
+        if (live && ab.nprim + ncd <= A.prim_lds) {
+            for (int x = lane; x < nb8; x += GSZ) pl[x] = prim_b[x];
+            for (int x = lane; x < nk8; x += GSZ) pl[nb8 + x] = prim_k[x];
+            prim_b = pl; prim_k = pl + nb8;
+        }
+        __syncthreads();
+    }
     double *wout = A.work + (size_t)tl * A.ncomp;
     int nPQ_all = nPQ; // uniform trip count over the quartets sharing this wave (the barriers below sit in the loop)
     if (QPW > 1)
@@ -828,7 +917,7 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
             if (lane < npq * 2 * n) {
                 int pql = lane / (2 * n), f = lane - pql * 2 * n;
                 int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
-                const double *b = A.prim + (size_t)(ab.prim_off + ip) * 8, *k = A.prim + (size_t)(cd.prim_off + jp) * 8;
+                const double *b = prim_b + (size_t)ip * 8, *k = prim_k + (size_t)jp * 8;
                 double p = b[0], q = k[0];
                 double dx = b[1] - k[1], dy = b[2] - k[2], dz = b[3] - k[3];
                 double x = p * q / (p + q) * (dx * dx + dy * dy + dz * dz);
@@ -839,7 +928,7 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
             if (lane < npq * n * 3) {
                 int pql = lane / (3 * n), rem = lane - pql * 3 * n, r = rem / 3, d = rem - r * 3;
                 int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
-                const double *b = A.prim + (size_t)(ab.prim_off + ip) * 8, *k = A.prim + (size_t)(cd.prim_off + jp) * 8;
+                const double *b = prim_b + (size_t)ip * 8, *k = prim_k + (size_t)jp * 8;
                 double p = b[0], q = k[0], pq1 = 1.0 / (p + q);
                 double u = rw[pql * 2 * n + r];
                 double PQd = b[1 + d] - k[1 + d];
@@ -899,6 +988,10 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // kernels, whose matrices are a few tens of rows/columns: one operand load per 16 FMAs instead of two per FMA).
 //   A(m,k) = A[m*sam + k*sak] for m < M, B(k,n) = B[k*sbk + n*sbn] for n < N, k < K; out-of-range elements read as 0.
 // Result layout: element r of the return value is C[m0 + (lane>>4) + 4r][n0 + (lane&15)].
+// Operand loads go out in chunks of WAVE_MFMA_CHUNK k steps before the chunk's MFMAs: the A / B operands of the per-quartet
+// transforms come from global memory (per-pair matrices) or LDS, and a load -> wait -> MFMA chain per k step made the kernels
+// latency bound (one ~1 us round trip per MFMA: 200 us for an (ff|fd) quartet).
+#define WAVE_MFMA_CHUNK 4
 __device__ inline d4_t wave_mfma_tile(const double *A, int sam, int sak, int M, const double *B, int sbk, int sbn, int N, int K, int m0,
                                       int n0, int lane)
 {
@@ -906,12 +999,18 @@ __device__ inline d4_t wave_mfma_tile(const double *A, int sam, int sak, int M, 
     const int m = m0 + (lane & 15), n = n0 + (lane & 15), kq = lane >> 4;
     const bool mv = m < M, nv = n < N;
     const double *pa = A + (size_t)(mv ? m : 0) * sam, *pb = B + (size_t)(nv ? n : 0) * sbn;
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + kq;
-        const bool kv = k < K;
-        const double a = (mv && kv) ? pa[(size_t)k * sak] : 0.0;
-        const double b = (nv && kv) ? pb[(size_t)k * sbk] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    for (int k0 = 0; k0 < K; k0 += 4 * WAVE_MFMA_CHUNK) {
+        double av[WAVE_MFMA_CHUNK], bv[WAVE_MFMA_CHUNK];
+#pragma unroll
+        for (int s_ = 0; s_ < WAVE_MFMA_CHUNK; s_++) {     // the chunk's operand loads go out together: one round trip per 16 k
+            const int k = k0 + 4 * s_ + kq;
+            const bool kv = k < K;
+            av[s_] = (mv && kv) ? pa[(size_t)k * sak] : 0.0;
+            bv[s_] = (nv && kv) ? pb[(size_t)k * sbk] : 0.0;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < WAVE_MFMA_CHUNK; s_++)
+            if (k0 + 4 * s_ < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s_], bv[s_], acc, 0, 0, 0);
     }
     return acc;
 }
@@ -947,6 +1046,11 @@ struct XfArgs {
     double *dense_out;
     int dense_mode, dense_n;
     int tri;                 // triangular rows in block-diagonal tiles (tile geometry)
+    const double *q_bra, *q_ket; // with qtol > 0: the same per-task Schwarz rejection as the Rys kernel made
+    double qtol;
+    unsigned xcd;            // XCD-aware block map (xcd_block)
+    int m_lds;               // 1: the two per-pair transformation matrices are staged in LDS with the E0 block (one memory round trip
+                             // for all operands; a global load per k step made the products a chain of dependent round trips)
 };
 
 // Read-only, wave-uniform operands (work-item records, tile directory, the J-L density rows) go through the
@@ -999,20 +1103,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     constexpr int QPW = 64 / GSZ;
     __shared__ int64_t tbase_all[QPW][8][16];   // tile base per (symmetry image, 2x2x2x2 sub-block of the quartet's AO ranges)
     const int grp = threadIdx.x / GSZ, lane = threadIdx.x % GSZ;
-    const int64_t tl = (int64_t)blockIdx.x * QPW + grp;
+    const int64_t tl = (int64_t)xcd_block(blockIdx.x, A.xcd) * QPW + grp;
     bool live = tl < A.ntask;
     int ib, ik;
     find_task(A.prefix, A.nbra, A.t0 + (live ? tl : 0), ib, ik);
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
+    if (A.qtol > 0.0 && A.q_bra[ib] * A.q_ket[ik] < A.qtol) live = false;
     if (A.check_owner)
         live = quartet_has_resident_tile(A.tile_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane, GSZ, grp) && live;
     if (QPW == 1 && !live) return;
     const double *E0g = A.work + (size_t)tl * A.ncomp;
-    double *E0 = lds_all + (size_t)grp * ((size_t)A.ne * A.nf + (size_t)A.nsab * A.nf); // [ne][nf]
+    const size_t lds_m = A.m_lds ? (size_t)2 * A.nsab * A.ne + (size_t)2 * A.nscd * A.nf : 0;
+    double *E0 = lds_all + (size_t)grp * ((size_t)A.ne * A.nf + (size_t)A.nsab * A.nf + lds_m); // [ne][nf]
     double *X = E0 + A.ne * A.nf;                                                       // [nsab][nf]
     // (M_ab / M_cd^T staged in LDS as well was measured SLOWER -- ibuprofen/def2-TZVP 0.325 -> 0.342 s: this kernel is bound by
     // its scattered tile stores, see DESIGN.md 3.2, and the larger LDS footprint only costs occupancy)
     const double *Mab = A.Mbuf + ab.m_off, *Mcd = A.Mbuf + cd.m_off;
+    if (A.m_lds) {   // M and M^T of both pairs, as stored (2 nsab ne and 2 nscd nf doubles)
+        double *ML = X + (size_t)A.nsab * A.nf;
+        const int na = 2 * A.nsab * A.ne, nc = 2 * A.nscd * A.nf;
+        if (live) {
+            for (int c = lane; c < na; c += GSZ) ML[c] = Mab[c];
+            for (int c = lane; c < nc; c += GSZ) ML[na + c] = Mcd[c];
+        }
+        Mab = ML; Mcd = ML + na;
+    }
     const double *MabT = Mab + A.nsab * A.ne, *McdT = Mcd + A.nscd * A.nf;   // [e][r], [f][c]
     if (live)
         for (int c = lane; c < A.ne * A.nf; c += GSZ) E0[c] = E0g[c];
@@ -1056,29 +1171,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
     }
     __syncthreads();
-    auto emit = [&](int r, int c, double s) {
-        int sa = r / A.nsb, sb = r - sa * A.nsb, sc = c / A.nsd, sd = c - sc * A.nsd;
-        int i = ab.ao_i + sa, j = ab.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
+    // Result block O[nsab][nscd] goes to LDS first (over E0, which is dead by then), then leaves for the tiles in ADDRESS order.
+    double *O = E0;
+    auto emit_dense = [&](int r, int c, double s) {   // density fitting: dense (ij|P) / (P|Q) output
+        int sa = r / A.nsb, sb = r - sa * A.nsb, sc = c / A.nsd;
+        int i = ab.ao_i + sa, j = ab.ao_j + sb, k = cd.ao_i + sc;
         if (A.dense_mode == 1) {
             A.dense_out[((size_t)i * A.nao + j) * A.dense_n + k] = s;
             A.dense_out[((size_t)j * A.nao + i) * A.dense_n + k] = s;
-            return;
-        }
-        if (A.dense_mode == 2) {
+        } else {
             A.dense_out[(size_t)i * A.dense_n + k] = s;
             A.dense_out[(size_t)k * A.dense_n + i] = s;
-            return;
         }
-        // sub-block of this element in the shells' own order (bit q: second block of shell q's AO range)
-        const int sub = ((i >> 3) - lo[0]) | (((j >> 3) - lo[1]) << 1) | (((k >> 3) - lo[2]) << 2) | (((l >> 3) - lo[3]) << 3);
-        if (mask & 1) put_tile_at(A, tbase[0][sub], i, j, k, l, s);
-        if (mask & 2) put_tile_at(A, tbase[1][sub], j, i, k, l, s);
-        if (mask & 4) put_tile_at(A, tbase[2][sub], i, j, l, k, s);
-        if (mask & 8) put_tile_at(A, tbase[3][sub], j, i, l, k, s);
-        if (mask & 16) put_tile_at(A, tbase[4][sub], k, l, i, j, s);
-        if (mask & 32) put_tile_at(A, tbase[5][sub], l, k, i, j, s);
-        if (mask & 64) put_tile_at(A, tbase[6][sub], k, l, j, i, s);
-        if (mask & 128) put_tile_at(A, tbase[7][sub], l, k, j, i, s);
     };
     // X = Mab E0, out = X Mcd^T: FP64 MFMA tiles for the large angular classes, per-lane dot products otherwise
     if (MFMA && GSZ == 64 && mfma_worthwhile(A.nsab, A.nf, A.ne)) {
@@ -1107,7 +1211,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     int r = m0 + (lane >> 4) + 4 * q, c = n0 + (lane & 15);
-                    if (r < A.nsab && c < A.nscd) emit(r, c, o4[q]);
+                    if (r < A.nsab && c < A.nscd) { if (A.dense_mode) emit_dense(r, c, o4[q]); else O[r * A.nscd + c] = o4[q]; }
                 }
             }
     } else if (live) {
@@ -1115,7 +1219,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             int r = o / A.nscd, c = o - r * A.nscd;
             double s = 0.0;
             for (int f = 0; f < A.nf; f++) s += X[r * A.nf + f] * McdT[f * A.nscd + c];
-            emit(r, c, s);
+            if (A.dense_mode) emit_dense(r, c, s); else O[o] = s;
+        }
+    }
+    if (A.dense_mode) return;
+    __syncthreads();
+    if (!live) return;
+    // Scatter, one symmetry image at a time, in the address order of the tile layout: a tile row is (j, l pair) and inside it
+    // the 16-byte chunks run over (i, k), so the lanes enumerate (j | l pair | i | k | l parity) of the image's roles -- one
+    // store instruction then covers runs of 2 n_k consecutive doubles per i (48 / 80 / 112 bytes for p / d / f kets) instead of
+    // 64 isolated doubles in 64 different rows, and the neighbouring kets (neighbouring tasks, same XCD: xcd_block) complete
+    // the lines.  Role tables: image bit 0 swaps the bra pair, bit 1 the ket pair, bit 2 exchanges bra and ket (numbering of
+    // `tbase`: 5 = (l,k,i,j), 6 = (k,l,j,i)).
+    {
+        const int n0_ = nsh[0], n1_ = nsh[1], n2_ = nsh[2], n3_ = nsh[3];
+#pragma unroll 1
+        for (int img = 0; img < 8; img++) {
+            if (!(mask & (1u << img))) continue;
+            // shell (0..3 = ab.i, ab.j, cd.i, cd.j) playing the i, j, k, l role of this image
+            const int ri = (0x32321010 >> (4 * img)) & 3, rj = (0x23230101 >> (4 * img)) & 3;
+            const int rk = (0x11003322 >> (4 * img)) & 3, rl = (0x00112233 >> (4 * img)) & 3;
+            auto pick = [](int a, int b, int c_, int d, int q) { return q == 0 ? a : (q == 1 ? b : (q == 2 ? c_ : d)); };
+            const int Ni = pick(n0_, n1_, n2_, n3_, ri), Nj = pick(n0_, n1_, n2_, n3_, rj), Nk = pick(n0_, n1_, n2_, n3_, rk),
+                      Nl = pick(n0_, n1_, n2_, n3_, rl);
+            const int Ai = pick(aos[0], aos[1], aos[2], aos[3], ri), Aj = pick(aos[0], aos[1], aos[2], aos[3], rj),
+                      Ak = pick(aos[0], aos[1], aos[2], aos[3], rk), Al = pick(aos[0], aos[1], aos[2], aos[3], rl);
+            const int p0 = Al >> 1, npair = ((Al + Nl - 1) >> 1) - p0 + 1;
+            const int row = Ni * Nk * 2, tot = Nj * npair * row;
+            const float inv_row = 1.0f / (float)row, inv_nk = 1.0f / (float)Nk, inv_np = 1.0f / (float)npair;
+            // position of each role's index inside O[(sa nsb + sb) nscd + sc nsd + sd] and inside the sub-block number
+            const int st_a = n1_ * A.nscd, st_b = A.nscd, st_c = n3_, st_d = 1;
+            const int Si = pick(st_a, st_b, st_c, st_d, ri), Sj = pick(st_a, st_b, st_c, st_d, rj), Sk = pick(st_a, st_b, st_c, st_d, rk),
+                      Sl = pick(st_a, st_b, st_c, st_d, rl);
+            const int Li = pick(lo[0], lo[1], lo[2], lo[3], ri), Lj = pick(lo[0], lo[1], lo[2], lo[3], rj), Lk = pick(lo[0], lo[1], lo[2], lo[3], rk),
+                      Ll = pick(lo[0], lo[1], lo[2], lo[3], rl);
+            for (int e = lane; e < tot; e += GSZ) {
+                int t = (int)(((float)e + 0.5f) * inv_row);          // (jb, mp) row; exact for these small integers
+                const int w = e - t * row;
+                const int par = w & 1, h = w >> 1;
+                const int ia = (int)(((float)h + 0.5f) * inv_nk), kc = h - ia * Nk;
+                const int jb = (int)(((float)t + 0.5f) * inv_np), mp = t - jb * npair;
+                const int labs = ((p0 + mp) << 1) + par;
+                if (labs < Al || labs >= Al + Nl) continue;
+                const double v = O[ia * Si + jb * Sj + kc * Sk + (labs - Al) * Sl];
+                const int gi = Ai + ia, gj = Aj + jb, gk = Ak + kc, gl = labs;
+                const int sub = (((gi >> 3) - Li) << ri) | (((gj >> 3) - Lj) << rj) | (((gk >> 3) - Lk) << rk) | (((gl >> 3) - Ll) << rl);
+                put_tile_at(A, tbase[img][sub], gi, gj, gk, gl, v);
+            }
         }
     }
 }
@@ -1150,6 +1300,9 @@ struct TpqArgs {
     XfArgs X;       // tile directory (tile_table, tile_off, tiles, nao) for put_tile
     const double *shell_xyz; // [nbas][3] shell centres (Bohr)
     int check_owner;
+    const double *q_bra, *q_ket; // per-task Schwarz rejection (qtol > 0), see EriArgs
+    double qtol;
+    unsigned xcd;            // XCD-aware block map (xcd_block)
 };
 
 // HRR + cart->sph of one shell pair applied to one index of a register array:
@@ -1234,10 +1387,11 @@ __global__ __launch_bounds__(TPQ_BLOCK) void eri_tpq_kernel(TpqArgs A)
         for (int q = threadIdx.x; q < ntab; q += TPQ_BLOCK) cheb[q] = src[q];
     }
     __syncthreads();
-    const int64_t tl = (int64_t)blockIdx.x * TPQ_BLOCK + threadIdx.x;
+    const int64_t tl = (int64_t)xcd_block(blockIdx.x, A.xcd) * TPQ_BLOCK + threadIdx.x;
     if (tl >= A.ntask) return;
     int ib, ik;
     find_task(A.prefix, A.nbra, A.t0 + tl, ib, ik);
+    if (A.qtol > 0.0 && A.q_bra[ib] * A.q_ket[ik] < A.qtol) return;
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
     constexpr int ni = 2 * LA + 1, nj = 2 * LB + 1, nk = 2 * LC + 1, nl = 2 * LD + 1;
     // block ranges of the four shells: which index images can land in a canonical tile, and is anything resident here
@@ -1502,6 +1656,26 @@ static void append_coarse_index(std::vector<int64_t> &prefix)
     }
 }
 
+// Task list of a (bra class, ket class) pair: bra b visits the leading kets of the (bound-ordered, see mi_eri_prepare step 3)
+// ket list whose bound cq can pass the Schwarz test with the bra's own q; inside one class only kets up to the bra itself
+// (canonical quartets).  `prefix` = cumulative counts + the coarse search index; returns the number of tasks.  Kets inside a
+// surviving cluster whose own q fails the test are rejected per task by the kernels (qtol).
+static int64_t class_prefix(const PairClass &B, const PairClass &Kc, bool same, double tol, std::vector<int64_t> &prefix)
+{
+    prefix.assign(B.recs.size() + 1, 0);
+    for (size_t b = 0; b < B.recs.size(); b++) {
+        const double thr = tol / B.q[b];
+        size_t lo = 0, hi = Kc.cq.size();
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (Kc.cq[mid] >= thr) lo = mid + 1; else hi = mid; }
+        int64_t cnt = (int64_t)lo;
+        if (same) cnt = std::min<int64_t>(cnt, (int64_t)b + 1);
+        prefix[b + 1] = prefix[b] + cnt;
+    }
+    const int64_t ntask = prefix.back();
+    append_coarse_index(prefix);
+    return ntask;
+}
+
 template <class T>
 static int upload(T **dst, const std::vector<T> &v)
 {
@@ -1521,6 +1695,7 @@ static int launch_eri(mi_ctx *c, EriArgs &E, int nblocks, hipStream_t st)
     // E.ntask tasks; the low angular classes run four quartets per wave (16 lanes each) unless their contraction depth
     // makes the four quartets of a wave too unequal: cost model in primitive batches per four quartets
     if (E.ntask != nblocks) return fail("launch_eri: ntask/grid mismatch");
+    if (nblocks < 2048) E.xcd = 0;   // too small for the chunked map to matter
     int perlane = (E.ncomp + 63) / 64;
     if (eri_small_class(E) && !E.diag && E.h_shared_np > 0.0) {
         const int pb16 = std::max(1, 16 / (3 * E.nroots)), pb64 = std::max(1, 64 / (3 * E.nroots));
@@ -1529,17 +1704,17 @@ static int launch_eri(mi_ctx *c, EriArgs &E, int nblocks, hipStream_t st)
         if (cost16 < cost64) {
             EriArgs G = E;
             G.PB = pb16;
-            size_t shm = 4 * sizeof(double) * ((size_t)G.PB * G.nroots * 3 * G.tsz + (size_t)G.PB * 2 * G.nroots);
-            hipLaunchKernelGGL((eri_rys_kernel<2, 16>), dim3((nblocks + 3) / 4), dim3(64), shm, st, G);
+            size_t shm = 4 * sizeof(double) * ((size_t)G.PB * G.nroots * 3 * G.tsz + (size_t)G.PB * 2 * G.nroots + (size_t)G.prim_lds * 8);
+            hipLaunchKernelGGL((eri_rys_kernel<2, 16>), dim3(eri_grid((nblocks + 3) / 4, G.xcd)), dim3(64), shm, st, G);
             HIPCHK(hipGetLastError());
             return 0;
         }
     }
-    size_t shm = sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots);
-    if (perlane <= 1) hipLaunchKernelGGL((eri_rys_kernel<1, 64>), dim3(nblocks), dim3(64), shm, st, E);
-    else if (perlane <= 4) hipLaunchKernelGGL((eri_rys_kernel<4, 64>), dim3(nblocks), dim3(64), shm, st, E);
-    else if (perlane <= 16) hipLaunchKernelGGL((eri_rys_kernel<16, 64>), dim3(nblocks), dim3(64), shm, st, E);
-    else hipLaunchKernelGGL((eri_rys_kernel<32, 64>), dim3(nblocks), dim3(64), shm, st, E);
+    size_t shm = sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots + (size_t)E.prim_lds * 8);
+    if (perlane <= 1) hipLaunchKernelGGL((eri_rys_kernel<1, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
+    else if (perlane <= 4) hipLaunchKernelGGL((eri_rys_kernel<4, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
+    else if (perlane <= 16) hipLaunchKernelGGL((eri_rys_kernel<16, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
+    else hipLaunchKernelGGL((eri_rys_kernel<32, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1561,12 +1736,14 @@ static int launch_eri_tpq_t(const TpqArgs &Q, hipStream_t st)
 {
     constexpr int NR = (LA + LB + LC + LD) / 2 + 1;
     const size_t shm = sizeof(double) * (size_t)RYS_NINT_H[NR] * 2 * NR * (RYS_DEG + 1);
-    const int64_t MAXB = (int64_t)1 << 30;
-    for (int64_t t0 = 0; t0 < Q.ntask; t0 += MAXB * TPQ_BLOCK) {   // grid.x stays below 2^31
+    const int64_t MAXB = (int64_t)1 << 24;
+    for (int64_t t0 = 0; t0 < Q.ntask; t0 += MAXB * TPQ_BLOCK) {   // grid.x stays well below 2^31 (also after the XCD-map rounding)
         TpqArgs P = Q;
         P.t0 = Q.t0 + t0;
         P.ntask = std::min<int64_t>(Q.ntask - t0, MAXB * TPQ_BLOCK);
-        hipLaunchKernelGGL((eri_tpq_kernel<LA, LB, LC, LD>), dim3((unsigned)((P.ntask + TPQ_BLOCK - 1) / TPQ_BLOCK)), dim3(TPQ_BLOCK), shm, st, P);
+        const int64_t nblk = (P.ntask + TPQ_BLOCK - 1) / TPQ_BLOCK;
+        if (nblk < 1024) P.xcd = 0;
+        hipLaunchKernelGGL((eri_tpq_kernel<LA, LB, LC, LD>), dim3(eri_grid(nblk, P.xcd)), dim3(TPQ_BLOCK), shm, st, P);
     }
     if (hipGetLastError() != hipSuccess) return fail("eri_tpq_kernel launch failed");
     return 1;
@@ -1666,6 +1843,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         t_phase = now;
     };
     free_eri(c);
+    if (set_tile_order(c, c->opt_ao_order ? 1 : 0)) return -1;
     const int nbas = c->nbas;
     std::vector<std::vector<double>> c2s(LMAX + 1);
     for (int l = 0; l <= LMAX; l++) c2s_generic(l, c2s[l]);
@@ -1777,13 +1955,45 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         PairClass &P = c->pc[ci];
         std::vector<int> ord(P.recs.size());
         std::iota(ord.begin(), ord.end(), 0);
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return P.q[a] > P.q[b]; });
+        // Order of the pair list.  Tasks are (bra, ket) with the ket index running fastest, and a bra only visits the leading
+        // kets whose bound can survive the Schwarz test, so the list must be non-increasing in a bound.  With `ket_cluster` that
+        // bound is the maximum q of the pair's CLUSTER -- the pairs whose first AOs fall into the same (block, block) pair of
+        // the store -- and inside a cluster the pairs follow their AO position: kets that complete one another's 64-byte lines
+        // of a tile (neighbouring k shells / l shells) are then neighbouring tasks, i.e. neighbouring lanes of the thread-per-
+        // quartet kernels and neighbouring workgroups of the others (which the XCD-aware block map keeps on one L2).
+        std::vector<double> cqv(P.recs.size());
+        std::vector<int64_t> cid(P.recs.size(), 0);
+        if (c->opt_ket_cluster) {
+            std::vector<std::pair<int64_t, double>> cm;   // cluster id -> max q over the surviving pairs
+            cm.reserve(P.recs.size());
+            for (size_t o = 0; o < P.recs.size(); o++) {
+                cid[o] = (int64_t)(P.recs[o].ao_i / BLK) * c->nblk + P.recs[o].ao_j / BLK;
+                if (P.q[o] * qmax >= tol) cm.push_back({cid[o], P.q[o]});
+            }
+            std::sort(cm.begin(), cm.end());
+            std::vector<std::pair<int64_t, double>> cmax;
+            for (const auto &e : cm) { if (cmax.empty() || cmax.back().first != e.first) cmax.push_back(e); else cmax.back().second = std::max(cmax.back().second, e.second); }
+            for (size_t o = 0; o < P.recs.size(); o++) {
+                auto it = std::lower_bound(cmax.begin(), cmax.end(), std::make_pair(cid[o], -1.0));
+                cqv[o] = (it != cmax.end() && it->first == cid[o]) ? it->second : P.q[o];
+            }
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+                if (cqv[a] != cqv[b]) return cqv[a] > cqv[b];
+                if (cid[a] != cid[b]) return cid[a] < cid[b];
+                if (P.recs[a].ao_i != P.recs[b].ao_i) return P.recs[a].ao_i < P.recs[b].ao_i;
+                return P.recs[a].ao_j < P.recs[b].ao_j;
+            });
+        } else {
+            for (size_t o = 0; o < P.recs.size(); o++) cqv[o] = P.q[o];
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return P.q[a] > P.q[b]; });
+        }
         std::vector<PairRec> r2;
-        std::vector<double> q2;
+        std::vector<double> q2, cq2;
         for (int o : ord) {
-            if (P.q[o] * qmax < tol) break;
+            if (P.q[o] * qmax < tol) { if (c->opt_ket_cluster) continue; else break; }
             r2.push_back(P.recs[o]);
             q2.push_back(P.q[o]);
+            cq2.push_back(cqv[o]);
             const PairRec &R = P.recs[o];
             int ni = 2 * P.la + 1, nj = 2 * P.lb + 1;
             for (int I = R.ao_i / BLK; I <= (R.ao_i + ni - 1) / BLK; I++)
@@ -1793,6 +2003,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                     Q = std::max(Q, P.q[o]);
                 }
         }
+        P.cq.swap(cq2);
         P.recs.swap(r2);
         P.q.swap(q2);
         if (upload(&P.d_recs, P.recs)) return -1;
@@ -1800,7 +2011,8 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         {
             double sm = 0.0, s4 = 0.0;
             const size_t np_ = P.recs.size();
-            for (size_t r = 0; r < np_; r++) sm += P.recs[r].nprim;
+            P.max_np = 1;
+            for (size_t r = 0; r < np_; r++) { sm += P.recs[r].nprim; P.max_np = std::max(P.max_np, P.recs[r].nprim); }
             for (size_t r = 0; r < np_; r += 4) {
                 int mx = 0;
                 for (size_t u = r; u < std::min(np_, r + 4); u++) mx = std::max(mx, P.recs[u].nprim);
@@ -1975,18 +2187,8 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         for (int kc = 0; kc <= bc; kc++) {
             PairClass &B = c->pc[bc], &Kc = c->pc[kc];
             if (B.recs.empty() || Kc.recs.empty()) continue;
-            std::vector<int64_t> prefix(B.recs.size() + 1, 0);
-            for (size_t b = 0; b < B.recs.size(); b++) {
-                double thr = tol / B.q[b];
-                // kets sorted descending: count q >= thr
-                size_t lo = 0, hi = Kc.q.size();
-                while (lo < hi) { size_t mid = (lo + hi) / 2; if (Kc.q[mid] >= thr) lo = mid + 1; else hi = mid; }
-                int64_t cnt = (int64_t)lo;
-                if (bc == kc) cnt = std::min<int64_t>(cnt, (int64_t)b + 1);
-                prefix[b + 1] = prefix[b] + cnt;
-            }
-            int64_t ntask = prefix.back();
-            append_coarse_index(prefix);
+            std::vector<int64_t> prefix;
+            const int64_t ntask = class_prefix(B, Kc, bc == kc, tol, prefix);
             if (ntask == 0) continue;
             nquart += ntask;
             if (prefix.size() > prefix_cap) {
@@ -2006,14 +2208,24 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             E.ni = 2 * B.la + 1; E.nj = 2 * B.lb + 1; E.nk = 2 * Kc.la + 1; E.nl = 2 * Kc.lb + 1;
             E.own_table = nranks > 1 ? c->d_tile_table : nullptr;
             E.h_shared_np = B.mean_np; E.h_vary_mean = Kc.mean_np; E.h_vary_max4 = Kc.max4_np;
+            E.q_bra = B.d_q; E.q_ket = Kc.d_q; E.qtol = c->opt_ket_cluster ? tol : 0.0;
+            E.prim_lds = (c->opt_prim_lds && B.max_np + Kc.max_np <= 160) ? B.max_np + Kc.max_np : 0;
+            const unsigned xcd_wave = c->opt_xcd_map ? 32u : 0u, xcd_tpq = c->opt_xcd_map ? 8u : 0u;
+            E.xcd = xcd_wave;
             XfArgs X{};
             X.bra = B.d_recs; X.ket = Kc.d_recs; X.Mbuf = c->d_M; X.prefix = d_prefix; X.nbra = E.nbra;
             X.ne = B.ne; X.nf = Kc.ne; X.nsab = B.nsab; X.nscd = Kc.nsab; X.nsb = 2 * B.lb + 1; X.nsd = 2 * Kc.lb + 1;
             X.work = d_work; X.ncomp = E.ncomp; X.tile_table = c->d_tile_table; X.tile_off = c->d_tile_off;
             X.tiles = c->d_tiles; X.nao = c->nao; X.tri = c->tri;
             X.check_owner = nranks > 1; X.ni = E.ni; X.nj = E.nj; X.nk = E.nk; X.nl = E.nl;
+            X.q_bra = E.q_bra; X.q_ket = E.q_ket; X.qtol = E.qtol; X.xcd = xcd_wave;
             int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
             size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
+            {
+                const size_t with_m = shm2 + sizeof(double) * ((size_t)2 * X.nsab * X.ne + (size_t)2 * X.nscd * X.nf);
+                X.m_lds = (c->opt_xf_mlds && with_m <= (size_t)c->opt_xf_mlds * 1024) ? 1 : 0;
+                if (X.m_lds) shm2 = with_m;
+            }
             // matrix-core path only for the large classes: below, the lean per-lane kernel (56 VGPRs, 8 waves per SIMD) hides the
             // per-quartet latency chain better than MFMA tiles at 3-4 waves per SIMD (measured per class on ibuprofen/def2-TZVP)
             const bool xf_mfma = (mfma_worthwhile(X.nsab, X.nf, X.ne) || mfma_worthwhile(X.nsab, X.nscd, X.nf)) &&
@@ -2034,6 +2246,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                 Q.c2s = c->d_c2s;
                 for (int q = 0; q <= LMAX + 1; q++) Q.c2s_off[q] = c->c2s_off[q];
                 Q.rys = c->rys; Q.X = X; Q.shell_xyz = c->d_shell_xyz; Q.check_owner = nranks > 1;
+                Q.q_bra = E.q_bra; Q.q_ket = E.q_ket; Q.qtol = E.qtol; Q.xcd = xcd_tpq;
                 auto ta = std::chrono::steady_clock::now();
                 if (dbg) hipStreamSynchronize(st);
                 const int used = launch_eri_tpq(B.la, B.lb, Kc.la, Kc.lb, Q, st);
@@ -2056,9 +2269,11 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                 if (launch_eri(c, E, nb, st)) return -1;
                 if (dbg) { hipStreamSynchronize(st); t_rys += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count(); ta = std::chrono::steady_clock::now(); }
                 X.ntask = nb;
-                if (xf_mfma) hipLaunchKernelGGL((eri_transform_scatter<true, 64>), dim3(nb), dim3(64), shm2, st, X);
-                else if (xf_small) hipLaunchKernelGGL((eri_transform_scatter<false, 16>), dim3((nb + 3) / 4), dim3(64), shm2 * 4, st, X);
-                else hipLaunchKernelGGL((eri_transform_scatter<false, 64>), dim3(nb), dim3(64), shm2, st, X);
+                X.xcd = nb >= 2048 ? xcd_wave : 0u;
+                E.xcd = xcd_wave;   // (launch_eri switches the map off for small launches)
+                if (xf_mfma) hipLaunchKernelGGL((eri_transform_scatter<true, 64>), dim3(eri_grid(nb, X.xcd)), dim3(64), shm2, st, X);
+                else if (xf_small) hipLaunchKernelGGL((eri_transform_scatter<false, 16>), dim3(eri_grid((nb + 3) / 4, X.xcd)), dim3(64), shm2 * 4, st, X);
+                else hipLaunchKernelGGL((eri_transform_scatter<false, 64>), dim3(eri_grid(nb, X.xcd)), dim3(64), shm2, st, X);
                 HIPCHK(hipGetLastError());
                 if (dbg) { hipStreamSynchronize(st); t_xf += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count(); }
             }
@@ -2071,6 +2286,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     if (d_prefix) hipFree(d_prefix);
     hipFree(d_work);
     hipFree(d_comp);
+    lap("free scratch");
     c->stats.n_tiles = c->n_tiles;
     c->stats.n_runs = (int64_t)c->runs.size();
     c->stats.stored_bytes = off * 8;
@@ -2141,7 +2357,7 @@ extern "C" int mi_df_build(mi_ctx *c, mi_ctx *aux, double *d_int3c, double *d_in
             const ShellH &I = c->shells[si], &J = c->shells[sj];
             double AB[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
             double r2 = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
-            PairRec R{si, sj, I.ao, J.ao, (int)(D.prim.size() / 8), 0, 0, 0};
+            PairRec R{si, sj, I.ao_nat, J.ao_nat, (int)(D.prim.size() / 8), 0, 0, 0};   // dense output in the caller's AO order
             for (int ip = 0; ip < I.nprim; ip++)
                 for (int jp = 0; jp < J.nprim; jp++) {
                     double a = I.exps[ip], b = J.exps[jp], p = a + b, mu = a * b / p;
@@ -2165,7 +2381,7 @@ extern "C" int mi_df_build(mi_ctx *c, mi_ctx *aux, double *d_int3c, double *d_in
     // auxiliary "pairs" (P, unit): p = alpha, centre P = A, P - A = 0, K = c_P * c_unit
     for (int Pn = 0; Pn < nP; Pn++) {
         const ShellH &S = aux->shells[Pn];
-        PairRec R{Pn, aux->nbas - 1, S.ao, unit_ao, (int)(D.prim.size() / 8), S.nprim, 0, 0};
+        PairRec R{Pn, aux->nbas - 1, S.ao_nat, unit_ao, (int)(D.prim.size() / 8), S.nprim, 0, 0};
         for (int ip = 0; ip < S.nprim; ip++) {
             double rec[8] = {S.exps[ip], S.r[0], S.r[1], S.r[2], 0.0, 0.0, 0.0, S.coef[ip] * U.coef[0]};
             D.prim.insert(D.prim.end(), rec, rec + 8);
@@ -2663,7 +2879,7 @@ __global__ __launch_bounds__(64) void jk_tiles_pipe_kernel(JkArgs A)
 // Dense (nao^4) copy of the resident tiles for post-SCF methods on small molecules (MP2 behind `pyscf.mp`): every stored
 // element is un-weighted (tiles hold 1/2 per block coincidence) and written to its eight symmetry images.
 __global__ __launch_bounds__(256) void eri_unpack_kernel(const double *tiles, const int64_t *tile_off, const TileInfo *info, int nao,
-                                                         int tri, double *out)
+                                                         int tri, double *out, const int *__restrict__ iperm)
 {
     const TileInfo T = info[blockIdx.x];
     const int bi = min(BLK, nao - T.I * BLK), bk = min(BLK, nao - T.K * BLK);
@@ -2674,12 +2890,13 @@ __global__ __launch_bounds__(256) void eri_unpack_kernel(const double *tiles, co
     for (int idx = threadIdx.x; idx < ntot; idx += blockDim.x) {
         const int ll = idx & 7, jj = (idx >> 3) & 7, pos = idx >> 6;
         const int ii = pos / bk, kk = pos - ii * bk;
-        const size_t i = T.I * BLK + ii, j = T.J * BLK + jj, k = T.K * BLK + kk, l = T.L * BLK + ll;
+        size_t i = T.I * BLK + ii, j = T.J * BLK + jj, k = T.K * BLK + kk, l = T.L * BLK + ll;
         if (j >= n1 || l >= n1) continue;
         double w;
         const int64_t e = tile_elem(tri != 0, T.I == T.J, T.K == T.L, bij == bkl, bi, bk, ii, jj, kk, ll, &w);
         if (e < 0) continue;                      // the (j,i) / (l,k) partner writes this image
         const double v = src[e] / w;
+        i = iperm[i]; j = iperm[j]; k = iperm[k]; l = iperm[l];   // tile order -> the caller's AO order
         out[i * n3 + j * n2 + k * n1 + l] = v; out[j * n3 + i * n2 + k * n1 + l] = v;
         out[i * n3 + j * n2 + l * n1 + k] = v; out[j * n3 + i * n2 + l * n1 + k] = v;
         out[k * n3 + l * n2 + i * n1 + j] = v; out[l * n3 + k * n2 + i * n1 + j] = v;
@@ -2699,7 +2916,7 @@ extern "C" int mi_eri_unpack(mi_ctx *c, double *d_out, void *stream)
     if (c->n_tiles == 0) return 0;
     TileInfo *d_info = nullptr;
     if (upload(&d_info, c->tiles)) return -1;
-    hipLaunchKernelGGL(eri_unpack_kernel, dim3((unsigned)c->n_tiles), dim3(256), 0, st, c->d_tiles, c->d_tile_off, d_info, c->nao, c->tri, d_out);
+    hipLaunchKernelGGL(eri_unpack_kernel, dim3((unsigned)c->n_tiles), dim3(256), 0, st, c->d_tiles, c->d_tile_off, d_info, c->nao, c->tri, d_out, c->d_iperm);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     hipFree(d_info);
@@ -2752,30 +2969,33 @@ extern "C" int mi_eri_read_quartet(mi_ctx *c, int ish, int jsh, int ksh, int lsh
     return 0;
 }
 
-__global__ void pad_density_kernel(const double *D, double *Dp, int nao, int ld)
+// `iperm`: tile AO -> caller AO (the padded copy is in the tile order of the ERI store)
+__global__ void pad_density_kernel(const double *D, double *Dp, int nao, int ld, const int *__restrict__ iperm)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ld * ld) return;
     int r = idx / ld, c = idx - r * ld;
-    Dp[idx] = (r < nao && c < nao) ? D[(size_t)r * nao + c] : 0.0;
+    Dp[idx] = (r < nao && c < nao) ? D[(size_t)iperm[r] * nao + iperm[c]] : 0.0;
 }
 
 // D -> zero-padded [ld][ld] copy, and the J/K accumulators cleared in the same launch (one kernel instead of three per build)
-__global__ void pad_density_clear_kernel(const double *D, double *Dp, double *Jacc, double *Kacc, int nao, int ld)
+__global__ void pad_density_clear_kernel(const double *D, double *Dp, double *Jacc, double *Kacc, int nao, int ld, const int *__restrict__ iperm)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ld * ld) return;
     int r = idx / ld, c = idx - r * ld;
-    Dp[idx] = (r < nao && c < nao) ? D[(size_t)r * nao + c] : 0.0;
+    Dp[idx] = (r < nao && c < nao) ? D[(size_t)iperm[r] * nao + iperm[c]] : 0.0;
     if (Jacc) Jacc[idx] = 0.0;
     if (Kacc) Kacc[idx] = 0.0;
 }
 
-__global__ void finalize_jk_kernel(const double *Jacc, const double *Kacc, double *J, double *K, int nao, int ld)
+// `perm`: caller AO -> tile AO (the accumulators are in tile order, J and K leave in the caller's)
+__global__ void finalize_jk_kernel(const double *Jacc, const double *Kacc, double *J, double *K, int nao, int ld, const int *__restrict__ perm)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nao * nao) return;
     int r = idx / nao, c = idx - r * nao;
+    r = perm[r]; c = perm[c];
     if (J) J[idx] = 2.0 * (Jacc[(size_t)r * ld + c] + Jacc[(size_t)c * ld + r]);
     if (K) K[idx] = Kacc[(size_t)r * ld + c] + Kacc[(size_t)c * ld + r];
 }
@@ -2816,7 +3036,7 @@ extern "C" int mi_build_jk(mi_ctx *c, const double *d_D, int n_dm, double *d_J, 
     if (n_dm == 2 && use_pair && c->n_tiles > 0) {
         for (int m = 0; m < 2; m++)
             hipLaunchKernelGGL(pad_density_clear_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D + m * nn, c->d_Dpad + m * pp,
-                               d_J ? c->d_Jacc + m * pp : nullptr, d_K ? c->d_Kacc + m * pp : nullptr, c->nao, c->ldp);
+                               d_J ? c->d_Jacc + m * pp : nullptr, d_K ? c->d_Kacc + m * pp : nullptr, c->nao, c->ldp, c->d_iperm);
         JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao,
                  c->n_jk_cached, c->tri, pp, 1};
         dim3 g(A.nruns), b(128);
@@ -2829,16 +3049,16 @@ extern "C" int mi_build_jk(mi_ctx *c, const double *d_D, int n_dm, double *d_J, 
         HIPCHK(hipGetLastError());
         for (int m = 0; m < 2; m++)
             hipLaunchKernelGGL(finalize_jk_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, c->d_Jacc + m * pp, c->d_Kacc + m * pp,
-                               d_J ? d_J + m * nn : nullptr, d_K ? d_K + m * nn : nullptr, c->nao, c->ldp);
+                               d_J ? d_J + m * nn : nullptr, d_K ? d_K + m * nn : nullptr, c->nao, c->ldp, c->d_perm);
         HIPCHK(hipGetLastError());
         return 0;
     }
     for (int m = 0; m < n_dm; m++) {
         hipLaunchKernelGGL(pad_density_clear_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D + m * nn, c->d_Dpad,
-                           d_J ? c->d_Jacc : nullptr, d_K ? c->d_Kacc : nullptr, c->nao, c->ldp);
+                           d_J ? c->d_Jacc : nullptr, d_K ? c->d_Kacc : nullptr, c->nao, c->ldp, c->d_iperm);
         if (launch_jk(c, d_J != nullptr, d_K != nullptr, st)) return -1;
         hipLaunchKernelGGL(finalize_jk_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, c->d_Jacc, c->d_Kacc,
-                           d_J ? d_J + m * nn : nullptr, d_K ? d_K + m * nn : nullptr, c->nao, c->ldp);
+                           d_J ? d_J + m * nn : nullptr, d_K ? d_K + m * nn : nullptr, c->nao, c->ldp, c->d_perm);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -2851,7 +3071,7 @@ extern "C" int mi_time_jk_variant(mi_ctx *c, const double *d_D, int with_j, int 
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     size_t pp = (size_t)c->ldp * c->ldp;
-    hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->nao, c->ldp);
+    hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->nao, c->ldp, c->d_iperm);
     HIPCHK(hipMemsetAsync(c->d_Jacc, 0, sizeof(double) * pp, st));
     HIPCHK(hipMemsetAsync(c->d_Kacc, 0, sizeof(double) * pp, st));
     hipEvent_t e0, e1;
@@ -5063,6 +5283,11 @@ static int launch_eri_tpq_grad(int l1, int l2, int lc, int ld, const TpqGradArgs
         TPQG_CASE(0, 0, 2, 0); TPQG_CASE(1, 0, 2, 0); TPQG_CASE(0, 1, 2, 0);
         TPQG_CASE(0, 0, 3, 0);
         TPQG_CASE(0, 0, 2, 1);
+        // round 3: candidates with up to ~150 accumulators (one wave per SIMD); kept only where the compiler needs no scratch
+        TPQG_CASE(0, 1, 1, 1); TPQG_CASE(1, 0, 3, 0); TPQG_CASE(0, 1, 3, 0); TPQG_CASE(1, 1, 2, 0);
+        TPQG_CASE(1, 0, 2, 1); TPQG_CASE(0, 1, 2, 1); TPQG_CASE(2, 0, 2, 0); TPQG_CASE(1, 2, 1, 0); TPQG_CASE(0, 2, 2, 0);
+        TPQG_CASE(2, 0, 1, 1); TPQG_CASE(0, 0, 3, 1); TPQG_CASE(0, 0, 2, 2);
+        TPQG_CASE(2, 1, 1, 0);
     default: return 0;
     }
 #undef TPQG_CASE
@@ -5121,11 +5346,11 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
     if (prepare_grad_records(c)) return -1;
     auto tg1 = std::chrono::steady_clock::now();
     size_t pp = (size_t)c->ldp * c->ldp;
-    hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->nao, c->ldp);
+    hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->nao, c->ldp, c->d_iperm);
     double *d_Mpad = nullptr; // spin density Da - Db, padded like D (open shell only)
     if (d_Dspin) {
         HIPCHK(hipMalloc(&d_Mpad, sizeof(double) * pp));
-        hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_Dspin, d_Mpad, c->nao, c->ldp);
+        hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_Dspin, d_Mpad, c->nao, c->ldp, c->d_iperm);
     }
     std::vector<int> shell_atom(c->nbas);
     for (int i = 0; i < c->nbas; i++) shell_atom[i] = c->shells[i].atom;
@@ -5162,17 +5387,8 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
         for (int kc = 0; kc <= bc; kc++) {
             PairClass &B = c->pc[bc], &Kc = c->pc[kc];
             if (B.recs.empty() || Kc.recs.empty()) continue;
-            std::vector<int64_t> prefix(B.recs.size() + 1, 0);
-            for (size_t b = 0; b < B.recs.size(); b++) {
-                double thr = tol / B.q[b];
-                size_t lo = 0, hi = Kc.q.size();
-                while (lo < hi) { size_t mid = (lo + hi) / 2; if (Kc.q[mid] >= thr) lo = mid + 1; else hi = mid; }
-                int64_t cnt = (int64_t)lo;
-                if (bc == kc) cnt = std::min<int64_t>(cnt, (int64_t)b + 1);
-                prefix[b + 1] = prefix[b] + cnt;
-            }
-            int64_t ntask = prefix.back();
-            append_coarse_index(prefix);
+            std::vector<int64_t> prefix;
+            const int64_t ntask = class_prefix(B, Kc, bc == kc, tol, prefix);
             if (ntask == 0) continue;
             if (prefix.size() > prefix_cap) {
                 if (d_prefix) hipFree(d_prefix);
@@ -5236,6 +5452,7 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                     Em.bra = Dc.d_g_recs[orient][1]; Em.ket = Oc.d_recs; Em.prim = c->d_prim; Em.prefix = d_prefix; Em.nbra = Ep.nbra;
                     Em.comp = d_comp_m; Em.work = d_wm; Em.rys = c->rys; Em.diag = 0; Em.swap = Ep.swap;
                 }
+                Ep.prim_lds = Em.prim_lds = (c->opt_prim_lds && B.max_np + Kc.max_np <= 160) ? B.max_np + Kc.max_np : 0;
                 Ep.h_shared_np = B.mean_np; Ep.h_vary_mean = Kc.mean_np; Ep.h_vary_max4 = Kc.max4_np;
                 Em.h_shared_np = B.mean_np; Em.h_vary_mean = Kc.mean_np; Em.h_vary_max4 = Kc.max4_np;
                 Ep.q_bra = Dc.d_q; Ep.q_ket = Oc.d_q; Ep.dmax = d_dmax; Ep.nbas_d = c->nbas; Ep.dtol = c->opt_grad_dtol; Ep.hyb = hyb;
@@ -5790,15 +6007,16 @@ extern "C" int mi_fock_energy(mi_ctx *c, const double *d_h, const double *d_J, c
 // -- one launch instead of finalize_jk_kernel + (V + V^T) + fock_energy_kernel, and 2 N^2 doubles less written and re-read.
 __global__ __launch_bounds__(256) void finalize_fock_kernel(const double *Jacc, const double *Kacc, int ld, const double *h,
                                                             const double *Vun, const double *D, double kscale, int nao, double *F,
-                                                            double *part)
+                                                            double *part, const int *__restrict__ perm)
 {
     __shared__ double sh[4];
     const size_t nn = (size_t)nao * nao, idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0.0;
     if (idx < nn) {
         const int r = (int)(idx / nao), c = (int)(idx - (size_t)r * nao);
-        const double j = 2.0 * (Jacc[(size_t)r * ld + c] + Jacc[(size_t)c * ld + r]);
-        const double k = Kacc ? Kacc[(size_t)r * ld + c] + Kacc[(size_t)c * ld + r] : 0.0;
+        const int pr = perm[r], pc = perm[c];     // the accumulators are in the tile order of the ERI store
+        const double j = 2.0 * (Jacc[(size_t)pr * ld + pc] + Jacc[(size_t)pc * ld + pr]);
+        const double k = Kacc ? Kacc[(size_t)pr * ld + pc] + Kacc[(size_t)pc * ld + pr] : 0.0;
         const double v2 = j - (Kacc ? kscale * k : 0.0);
         const double hh = h[idx];
         F[idx] = hh + v2 + (Vun ? Vun[idx] + Vun[(size_t)c * nao + r] : 0.0);
@@ -5819,10 +6037,10 @@ extern "C" int mi_build_fock(mi_ctx *c, const double *d_D, const double *d_h, co
     hipStream_t st = (hipStream_t)stream;
     const size_t nn = (size_t)c->nao * c->nao, pp = (size_t)c->ldp * c->ldp;
     hipLaunchKernelGGL(pad_density_clear_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->d_Jacc,
-                       with_k ? c->d_Kacc : nullptr, c->nao, c->ldp);
+                       with_k ? c->d_Kacc : nullptr, c->nao, c->ldp, c->d_iperm);
     if (launch_jk(c, true, with_k != 0, st)) return -1;
     hipLaunchKernelGGL(finalize_fock_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, c->d_Jacc, with_k ? c->d_Kacc : nullptr,
-                       c->ldp, d_h, d_Vun, d_D, kscale, c->nao, d_F, d_part);
+                       c->ldp, d_h, d_Vun, d_D, kscale, c->nao, d_F, d_part, c->d_perm);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -106,6 +106,7 @@ def lib():
         L.mi_eri_get_memory.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.mi_eri_release.argtypes = [vp]
         L.mi_tile_store_allocations.restype = ctypes.c_int64
+        L.mi_tile_store_allocations.argtypes = [ctypes.c_int64]
         L.mi_eri_read_quartet.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
         L.mi_schwarz_get.argtypes = [vp, dp]
         L.mi_df_build.argtypes = [vp, vp, vp, vp, vp]
@@ -130,9 +131,9 @@ def plan_shards(nao, qblk, tol, nranks):
     return b, r
 
 
-def tile_store_allocations():
-    """Fresh device allocations of tile stores made by this process (reuse of a parked store does not count)."""
-    return int(lib().mi_tile_store_allocations())
+def tile_store_allocations(min_bytes=0):
+    """Fresh device allocations of tile stores >= `min_bytes` made by this process (reuse of a parked store does not count)."""
+    return int(lib().mi_tile_store_allocations(int(min_bytes)))
 
 
 def release_cache():

@@ -161,6 +161,7 @@ class SCF:
     # broadcast once per cycle and every rank decides from that copy; False = no broadcast (zero per-cycle collectives beside
     # the Fock all-reduce; the world-2 tests assert bit-identical energies in this mode); True = always.
     sync_control = None
+    host_cholesky_max = 400   # basis sizes up to which S = L L^T and L^-1 are formed on the host (see _setup)
     level_shift = 0.0    # Hartree; virtual-orbital shift applied to the Fock matrix that is diagonalised / purified
 
     def __init__(self, mol):
@@ -270,9 +271,21 @@ class SCF:
             parallel.broadcast0(hs, self._pg)
             S, h1 = hs[0].contiguous(), hs[1].contiguous()
         self._S, self._h1 = S, h1
-        L = torch.linalg.cholesky(S)
+        if eng.nao <= self.host_cholesky_max:
+            # S = L L^T and L^-1 on the HOST for small bases (LAPACK, 4-6 ms at N = 264): the first rocSOLVER call of a process costs
+            # ~0.13 s of lazy initialisation (tools/wall_profile.py), a third of a cold benzene/cc-pVTZ kernel(); the warm-up
+            # thread (engine._warm_libraries) has the device solver ready by the time the final eigh needs it.  Few BLAS
+            # threads: an unlimited pool on a many-core host takes 50x longer on these sizes than four threads do.
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=4):
+                Lh = np.linalg.cholesky(S.cpu().numpy())    # raises numpy.linalg.LinAlgError for a linearly dependent basis
+                Li = np.linalg.inv(Lh)
+            L = torch.from_numpy(np.ascontiguousarray(Lh)).to(eng.device)
+            self._Linv = torch.from_numpy(np.ascontiguousarray(np.tril(Li))).to(eng.device)
+        else:
+            L = torch.linalg.cholesky(S)
+            self._Linv = torch.linalg.solve_triangular(L, torch.eye(eng.nao, dtype=torch.float64, device=eng.device), upper=False)
         self._L = L
-        self._Linv = torch.linalg.solve_triangular(L, torch.eye(eng.nao, dtype=torch.float64, device=eng.device), upper=False)
         if getattr(self, "with_df", None) is not None:
             if self.with_df.mol is not self.mol or self.with_df._B is None:
                 self.with_df.mol = self.mol

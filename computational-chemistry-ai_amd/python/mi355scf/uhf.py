@@ -145,7 +145,7 @@ class UHF(SCF):
         small = n < self.sp2_min_nao or self.eig_method != "sp2"
         warm = all(no == 0 or sp.vals["_sp2_plan"] is not None for sp, no in zip(self._spin_states(n), (na, nb)))
         use_fast = self.fast_loop and (small or (self.fast_loop == "always" and warm))
-        if use_fast and not self._sync_control_on():
+        if use_fast:
             return self._kernel_fast(dm0)
         return self._kernel_plain(dm0)
 
@@ -237,6 +237,9 @@ class UHF(SCF):
             diis.push_inplace()
         parts = [e_el.reshape(1), part] + [t for t in trs if t is not None]
         packed = torch.cat(parts)
+        if self._sync_control_on():     # sharded: rank 0's control scalars are everybody's (see scf.SCF.sync_control)
+            from . import parallel
+            parallel.broadcast0(packed, self._pg)
         ctx = dict(dm=dm, dmo=dmo, F=F, fo=fo, nb=nb, packed=packed, tr_sizes=[0 if t is None else t.numel() for t in trs], event=None)
         k = packed.numel()
         if k <= self._PIN_DOUBLES:

@@ -87,9 +87,10 @@ int mi_eri_get_memory(const mi_ctx *ctx, int64_t *need_bytes, int64_t *free_byte
 /* Drop the resident store of the last mi_eri_prepare (parked for reuse by the next one).  A sharded run whose ranks agree on
  * the direct mode (because SOME rank's shard did not fit) calls this on the ranks whose shard did fit. */
 int mi_eri_release(mi_ctx *ctx);
-/* Fresh device allocations of tile stores made by this process so far (re-use of the parked store of a destroyed / released
- * context does not count): every step of optimize(mf) (templates/optimize_geometry.py:99) should reuse ONE allocation. */
-int64_t mi_tile_store_allocations(void);
+/* Fresh device allocations of tile stores of at least `min_bytes` made by this process so far (re-use of the parked store of
+ * a destroyed / released context does not count): every step of optimize(mf) (templates/optimize_geometry.py:99) should reuse
+ * ONE allocation. */
+int64_t mi_tile_store_allocations(int64_t min_bytes);
 
 /* Sharding plan without a GPU or a context: the (J,K,L) tile runs that survive the block-pair Schwarz table
  * qblk[nblk(nblk+1)/2] (nblk = ceil(nao/8); entry I(I+1)/2+J = max Schwarz factor of the shell pairs touching AO blocks I,J)

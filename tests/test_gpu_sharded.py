@@ -107,11 +107,10 @@ def test_two_rank_sharded_scf_matches_single(method):
     # auto-on) until a multi-GPU run has confirmed the bit-identity; the "-nosync" cases keep the zero-broadcast mode covered.
     for r in res:
         assert r[6]["sync"] == ("sync_control" not in opts)
-        nb = r[6]["fock_builds"] if (r[6]["sync"] and not method.startswith("U")) else 0
-        if r[6]["sync"] and method.startswith("U"):
-            assert r[6]["broadcast"] > 2, r[6]    # plain UHF/UKS loop: Gram row + control scalars per cycle
-        else:
-            assert r[6]["broadcast"] == 2 + nb, r[6]   # set-up: [S|h] and the starting density, whatever the number of cycles
+        nb = r[6]["fock_builds"] if r[6]["sync"] else 0
+        # set-up: [S|h] and the starting density, whatever the number of cycles (+ one per Fock build with sync_control; the
+        # open-shell loop's final build, whose scalars steer nothing, goes without)
+        assert 2 + nb - (1 if method.startswith("U") and nb else 0) <= r[6]["broadcast"] <= 2 + nb, r[6]
         assert r[6]["all_reduce"] == r[6]["fock_builds"], r[6]
     assert res[0][7] == res[1][7], (res[0][7], res[1][7])
 
