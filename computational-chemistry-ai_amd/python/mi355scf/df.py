@@ -62,7 +62,11 @@ class DF:
         self._B = None
         self.auxmol = None
 
-    def build(self, engine):
+    def build(self, engine, rank=0, nranks=1):
+        """Evaluate (ij|P), (P|Q) and keep the whitened tensor B.  `rank`/`nranks`: a sharded run keeps only ITS contiguous
+        slice of the whitened auxiliary index, B[i, P_r, j] (1 / nranks of the memory and of the J/K work): rho_P, J and K are
+        sums over P, so every rank's partial J, K enter the Fock all-reduce like the partials of the four-centre tile shards.
+        (The three-index integrals themselves are evaluated by every rank: the whitening mixes all Q into each P.)"""
         mol = self.mol
         basis = self.auxbasis if isinstance(self.auxbasis, dict) else even_tempered_aux(mol, self.beta)
         if isinstance(self.auxbasis, str) and self.auxbasis:
@@ -92,10 +96,14 @@ class DF:
         L = torch.linalg.cholesky(int2c)
         # fitted tensor B[i, P, j] = sum_Q L^-1[P, Q] (Q|ij), stored i-major: the exchange build is then two plain GEMMs
         Linv = torch.linalg.solve_triangular(L, torch.eye(na, dtype=torch.float64, device=engine.device), upper=False)
-        self._B = torch.empty(n, na, n, dtype=torch.float64, device=engine.device)                     # [i, P, j]
+        from .parallel import split_range
+        p0, p1 = split_range(na, rank, nranks) if nranks > 1 else (0, na)
+        self.aux_slice = (p0, p1)
+        Lr = Linv[p0:p1].contiguous()
+        self._B = torch.empty(n, p1 - p0, n, dtype=torch.float64, device=engine.device)                # [i, P (this rank's), j]
         step = max(1, int(1.0e9 / (8.0 * na * n)))
         for i0 in range(0, n, step):      # B[i] = L^-1 (Q|i j)^T as batched GEMMs, a slab of i at a time
-            torch.matmul(Linv, int3c[i0:i0 + step].transpose(1, 2), out=self._B[i0:i0 + step])
+            torch.matmul(Lr, int3c[i0:i0 + step].transpose(1, 2), out=self._B[i0:i0 + step])
         del int3c
         self._eng = engine
         return self

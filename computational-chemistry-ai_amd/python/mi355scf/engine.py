@@ -566,14 +566,12 @@ def _warm_libraries(device, n=32, nocc=24):
                 with torch.cuda.stream(s):
                     n_ = int(max(8, min(n, 1024)))
                     a = torch.eye(n_, dtype=torch.float64, device=device) * 2.0 + 0.01 / n_
-                    torch.linalg.eigh(a)
-                    r, _ = torch.linalg.cholesky_ex(a)
-                    torch.linalg.solve_triangular(r, a, upper=False)
+                    # in the order the SCF needs them: the loop's GEMMs / element-wise kernels first (needed ~0.2 s into a cold
+                    # benzene run), the solver last (eigh: only after convergence; its initialisation alone takes ~0.15 s)
                     (a @ a).sum()
                     torch.addmm(a, a, a, beta=0.5, alpha=0.5)
-                    m_ = int(max(1, min(nocc, n_)))        # the n_occ-sized factorisation / products of the low-rank XC densities
-                    r2, _ = torch.linalg.cholesky_ex(a[:m_, :m_].contiguous())
-                    torch.linalg.solve_triangular(r2, a[:m_, :].contiguous(), upper=False)
+                    torch.matmul(a @ a, a.T, out=torch.empty_like(a))
+                    m_ = int(max(1, min(nocc, n_)))        # the n_occ-sized products of the low-rank XC densities
                     (a[:, :m_].T @ a)
                     w_ = a @ a[:, :m_]
                     (a[:, :m_].T @ w_)
@@ -583,8 +581,15 @@ def _warm_libraries(device, n=32, nocc=24):
                     torch.stack([torch.trace(a), torch.sum(a * a)])
                     a.diagonal().add_(0.0)
                     (a + a.T).mul_(0.5)
+                    (2.0 * a)
                     torch.where(torch.isfinite(a).all(), a, a)
                     torch.empty(64, dtype=torch.float64).pin_memory()
+                    s.synchronize()
+                    torch.linalg.eigh(a)
+                    r, _ = torch.linalg.cholesky_ex(a)
+                    torch.linalg.solve_triangular(r, a, upper=False)
+                    r2, _ = torch.linalg.cholesky_ex(a[:m_, :m_].contiguous())
+                    torch.linalg.solve_triangular(r2, a[:m_, :].contiguous(), upper=False)
                 s.synchronize()
         except Exception:
             pass

@@ -290,7 +290,7 @@ class SCF:
             if self.with_df.mol is not self.mol or self.with_df._B is None:
                 self.with_df.mol = self.mol
                 t1 = time.time()
-                self.with_df.build(eng)
+                self.with_df.build(eng, self._rank, self._nranks)
                 torch.cuda.synchronize()
                 self.timing["df_seconds"] = time.time() - t1
                 self._log(4, f"density fitting: {self.with_df.naux} auxiliary functions, tensor "
@@ -416,8 +416,12 @@ class SCF:
         return J, K   # pair records / Schwarz data of the last group stay valid (used by the gradient)
 
     def _jk(self, dm, with_j=True, with_k=True):
-        if getattr(self, "with_df", None) is not None:     # fitted integrals: dense GEMMs on the resident B tensor, replicated
-            return self.with_df.get_jk(dm, with_j, with_k)
+        if getattr(self, "with_df", None) is not None:     # fitted integrals: dense GEMMs on this rank's slice of the resident B tensor
+            J, K = self.with_df.get_jk(dm, with_j, with_k)
+            if self._nranks > 1:
+                from . import parallel
+                parallel.all_reduce_fused([x for x in (J, K) if x is not None], self._pg)
+            return J, K
         if self._stream_groups > 1:
             J, K = self._jk_streamed(dm, with_j, with_k)
         else:
@@ -435,11 +439,10 @@ class SCF:
         """This rank's PARTIAL J (and K unless None) written into caller-owned views, no collective: the caller all-reduces
         the buffer the views live in (Kohn-Sham: one fused [J|K|Vxc|N|Exc] collective per Fock build)."""
         if getattr(self, "with_df", None) is not None:
-            j, k = self.with_df.get_jk(dm, True, K is not None)
-            scale = 1.0 / self._nranks       # replicated fit: every rank adds its share so that the all-reduce restores J, K
-            J.copy_(j * scale)
+            j, k = self.with_df.get_jk(dm, True, K is not None)   # partial sums over this rank's slice of the auxiliary index
+            J.copy_(j)
             if K is not None:
-                K.copy_(k * scale)
+                K.copy_(k)
             return
         if self._stream_groups > 1:
             j, k = self._jk_streamed(dm, True, K is not None)
@@ -861,6 +864,8 @@ class SCF:
                   de=(e_tot - e_last) if e_last is not None else 0.0)
         return True
 
+    cold_pipeline = True   # first SCF of an object: pipelined, optimistic trace-correcting purification (no plan needed)
+    cold_margin = 6        # extra purification passes queued while |g| > sp2_plan_gnorm (the needed count still moves)
     pipeline = True   # queue the device-only head of cycle k+1 (extrapolation, purification, density) before waiting for cycle k's scalars
 
     def _front(self, st):
@@ -870,16 +875,29 @@ class SCF:
         cycle cannot take the planned path."""
         nocc = st["nocc"]
         n = self._Linv.shape[0]
-        if not (self.pipeline and self.eig_method == "sp2" and self.sp2_planned and self._sp2_plannable(n)
-                and 0 < nocc < n and not self.level_shift and self._sp2_plan is not None
-                and st.get("gnorm", 0.0) <= self.sp2_plan_gnorm
+        if not (self.pipeline and self.eig_method == "sp2" and 0 < nocc < n and not self.level_shift
                 and st["cycle"] + 1 >= self.diis_start_cycle and st["diis"].count > 0):
             return None
+        planned = (self.sp2_planned and self._sp2_plannable(n) and self._sp2_plan is not None
+                   and st.get("gnorm", 0.0) <= self.sp2_plan_gnorm)
+        # a COLD object (first kernel() of the object: no plan yet, see `sp2_plan_inloop`) pipelines too: the trace-correcting
+        # purification needs no spectral bounds, only a pass count -- the one the previous cycle needed plus a margin that is
+        # generous while the spectrum still moves (a pass costs 7 us, a redone cycle a whole Fock build)
+        cold = (not planned and self.cold_pipeline and self._sp2_validated and n <= self.sp2_fused_max and self.sp2_fused
+                and (self._sp2_plan is None or st.get("gnorm", 0.0) > self.sp2_plan_gnorm))
+        if not (planned or cold):
+            return None
         fo = st["diis"].extrapolate()
-        dmo, tr_dev = self._sp2_planned_async(fo, nocc)
+        if planned:
+            dmo, tr_dev = self._sp2_planned_async(fo, nocc)
+        else:
+            keep = self._sp2_iters
+            self._sp2_iters = min(keep + (self.cold_margin if st.get("gnorm", 0.0) > self.sp2_plan_gnorm else 0), 72)
+            dmo, tr_dev = self._sp2_fused_async(fo, nocc)
+            self._sp2_iters = keep
         shape, self._sp2_hist_shape = self._sp2_hist_shape, None
         dm = (self._Linv.T @ dmo @ self._Linv).contiguous()
-        return dict(fo=fo, dmo=dmo, dm=dm, tr=tr_dev, shape=shape)
+        return dict(fo=fo, dmo=dmo, dm=dm, tr=tr_dev, shape=shape, planned=planned)
 
     def _step(self, st, use_diis=True, want_mo=False):
         """One SCF cycle: CDIIS extrapolation -> occupied projector (SP2 or eigh) -> density -> J/K ->
@@ -893,7 +911,7 @@ class SCF:
         self._sp2_planned_pass = False
         if front is not None:
             fo, dmo, tr_dev, hist_shape, dm = front["fo"], front["dmo"], front["tr"], front["shape"], front["dm"]
-            self._sp2_planned_pass = True
+            self._sp2_planned_pass = bool(front.get("planned", True))
             planned_ok = True
             st.pop("mo_e", None)
         else:
@@ -926,9 +944,15 @@ class SCF:
                 # each a diagonalisation and a second Fock build).  Checked purification until the SCF has settled.
                 dmo = self._density_sp2(fo, nocc, orth=True)
             elif early and st.get("gnorm", 0.0) > self.sp2_plan_gnorm:
-                # checked purification (validated on the host inside, iteration count adapted there): while the spectrum still
-                # moves from cycle to cycle the optimistic variant would guess the count wrong and cost a redo cycle
-                dmo = self._density_sp2(fo, nocc, orth=True)
+                if self.cold_pipeline and self._sp2_validated and not st.get("_redo") and n <= self.sp2_fused_max and self.sp2_fused:
+                    # optimistic: last count + a generous margin, validated with the cycle's scalars (no host sync here)
+                    keep = self._sp2_iters
+                    self._sp2_iters = min(keep + self.cold_margin, 72)
+                    dmo, tr_dev = self._sp2_fused_async(fo, nocc)
+                    self._sp2_iters = keep
+                else:
+                    # checked purification (validated on the host inside, iteration count adapted there)
+                    dmo = self._density_sp2(fo, nocc, orth=True)
             elif early and self._sp2_validated and not st.get("_redo"):
                 dmo, tr_dev = self._sp2_fused_async(fo, nocc)     # settled, but no plan on this object yet (see sp2_plan_inloop)
             elif early:

@@ -161,3 +161,46 @@ def test_benzene_b3lyp_frequencies_ir_and_thermo_against_literature():
     assert abs(t["ZPE"][0] * 627.509 - 63.3) < 0.5
     assert t["sym_number"][0] == 12
     assert abs(t["S_tot"][0] * 627509 - 64.3) < 1.0
+
+
+def test_water_hessian_matches_second_differences_of_the_oracle_energy():
+    """Parity (not self-consistency): every element of the semi-numerical HIP Hessian of H2O RHF/6-31G against second
+    differences of the CPU ORACLE's SCF energy (McMurchie-Davidson integrals, numpy SCF: a different code path end to end).
+    H_ij = [E(+i+j) - E(+i-j) - E(-i+j) + E(-i-j)] / 4 h^2 with h = 0.02 Bohr (truncation ~h^2 E'''' / 6 ~ 1e-5, energy noise
+    1e-12 / 4 h^2 ~ 1e-9), diagonal by the three-point formula; tolerance 5e-5 Hartree/Bohr^2 on elements of order 0.1-0.7."""
+    from pyscf import gto, scf, hessian
+    from oracle import oracle as orc
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.verbose = "O 0 0 0.1; H 0 -0.76 0.59; H 0 0.74 0.60", "6-31G", 0   # no symmetry: every element distinct
+    mol.build()
+    mf = scf.RHF(mol)
+    mf.conv_tol = 1e-12
+    mf.kernel()
+    hess = hessian.RHF(mf).kernel()
+    n = mol.natm
+    H = hess.transpose(0, 2, 1, 3).reshape(3 * n, 3 * n)
+    R = mol.atom_coords().ravel()
+    h = 0.02
+
+    def e_orc(dx):
+        m2 = mol.set_geom_((R + dx).reshape(-1, 3), unit="Bohr", inplace=False)
+        m2.verbose = 0
+        r = orc.rhf(m2, conv_tol=1e-13, max_cycle=100)
+        assert r["converged"]
+        return r["e_tot"]
+
+    e0 = e_orc(np.zeros_like(R))
+    assert abs(e0 - mf.e_tot) < 1e-8
+    Ho = np.zeros_like(H)
+    ep, em = np.zeros(3 * n), np.zeros(3 * n)
+    for i in range(3 * n):
+        d = np.zeros_like(R); d[i] = h
+        ep[i], em[i] = e_orc(d), e_orc(-d)
+        Ho[i, i] = (ep[i] - 2.0 * e0 + em[i]) / h ** 2
+    for i in range(3 * n):
+        for j in range(i):
+            di = np.zeros_like(R); di[i] = h
+            dj = np.zeros_like(R); dj[j] = h
+            Ho[i, j] = Ho[j, i] = (e_orc(di + dj) - e_orc(di - dj) - e_orc(dj - di) + e_orc(-di - dj)) / (4.0 * h ** 2)
+    assert np.abs(Ho).max() > 0.3
+    assert np.abs(H - Ho).max() < 5e-5, np.abs(H - Ho).max()

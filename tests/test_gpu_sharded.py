@@ -22,6 +22,7 @@ def _worker(rank, world, port, method, q, opts=None):
 
 
 def _worker_body(rank, world, port, method, q, opts):
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "computational-chemistry-ai_amd", "python"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -41,6 +42,8 @@ def _worker_body(rank, world, port, method, q, opts):
         mf.xc = method.lstrip("U")
     mf.conv_tol = 1e-10
     mf.shard(rank, world)
+    if opts.get("df"):
+        mf = mf.density_fit()
     if "sync_control" in opts:
         mf.sync_control = opts["sync_control"]
     if "memory_views" in opts:      # (oom, need_bytes, free_bytes) this rank pretends to have seen in mi_eri_prepare
@@ -55,7 +58,11 @@ def _worker_body(rank, world, port, method, q, opts):
         gs = mf._group_stats
         assert sorted(gs) == list(range(mf._stream_groups)), sorted(gs)
         st = {k: sum(g[k] for g in gs.values()) for k in ("n_tiles", "n_unique_eri")}
-    g = mf.nuc_grad_method().kernel()
+    if opts.get("df"):
+        st = {"n_tiles": int(mf.with_df._B.shape[1]), "n_unique_eri": int(mf.with_df.naux)}   # this rank's auxiliary slice
+        g = np.zeros((mol.natm, 3))
+    else:
+        g = mf.nuc_grad_method().kernel()
     q.put((rank, e, bool(mf.converged), st["n_tiles"], st["n_unique_eri"], g.tolist(), coll, float(e).hex()))
     import torch.distributed as dist
     dist.destroy_process_group()
@@ -270,3 +277,35 @@ def test_direct_mode_gradient_matches_resident():
         g3 = mf3.nuc_grad_method().kernel()
         assert mf3.converged and np.abs(g3 - g1).max() < 1e-8, np.abs(g3 - g1).max()
         assert np.abs(g1).max() > 1e-3
+
+
+
+def test_two_rank_density_fitting_shards_the_auxiliary_index():
+    """`mf.density_fit()` on two ranks: each keeps half of the whitened auxiliary index of B[i,P,j]; partial J / K are summed by
+    the one Fock all-reduce; the energy equals the single-rank fitted energy."""
+    from pyscf import gto, scf
+    mol = gto.Mole()
+    mol.atom = MOLECULES["h2co"]
+    mol.basis = "6-31G(d)"
+    mol.verbose = 0
+    mol.build()
+    mf = scf.RHF(mol).density_fit()
+    mf.conv_tol = 1e-10
+    e1 = mf.kernel()
+    naux = mf.with_df.naux
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, "HF", q, {"df": True})) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert not any(r[1] == "error" for r in res), [r[2] for r in res if r[1] == "error"]
+    assert all(r[2] for r in res) and abs(res[0][1] - e1) < 5e-9 and res[0][7] == res[1][7]
+    assert res[0][3] + res[1][3] == naux and min(res[0][3], res[1][3]) > 0 and res[0][4] == naux
+    for r in res:
+        assert r[6]["all_reduce"] == r[6]["fock_builds"], r[6]
