@@ -364,6 +364,18 @@ def main():
                 leg(e2, mol2.nao, st2, (a + a.T).cuda(), "benzene/cc-pVDZ", ((True, False, "J only", 2), (True, True, "J+K", 3)))
                 e2.close()
 
+    # a second, COLD object in the now warm process (libraries loaded, ERIs resident): the cycles of the one kernel() call the
+    # reference's scripts make, without this process's first-use costs (those are in `first_scf` and in `wall_clock`)
+    cold_obj = None
+    if world == 1 and not direct_mode:
+        mf2 = RHF(mol)
+        mf2.eig_method = args.eig
+        mf2._eng = mf.engine
+        mf2.kernel()
+        torch.cuda.synchronize()
+        cold_obj = {"cycles": mf2.cycles, "loop_seconds": mf2.timing.get("loop_seconds"), "converged": bool(mf2.converged),
+                    "ms_per_cycle": mf2.timing.get("loop_seconds", 0.0) / max(mf2.cycles, 1) * 1e3, "e_tot": mf2.e_tot}
+
     scale_leg = None
     if not args.no_scale_leg and args.molecule == "benzene" and not direct_mode:
         scale_leg = ibuprofen_leg(args, world, rank, barrier)
@@ -380,12 +392,15 @@ def main():
                           "settle_cycles_before_warmup": SETTLE,
                           "redone_cycles": getattr(mf, "n_redo", 0),
                           # the call the reference's scripts make is ONE kernel() on a fresh object: its own cycles, averaged
-                          "cold_ms_per_cycle": first_scf["ms_per_cycle_incl_first_use"],
-                          "cold_iter_per_s": 1e3 / max(first_scf["ms_per_cycle_incl_first_use"], 1e-9),
-                          "cold_cycles": first_scf["cycles"],
+                          "cold_ms_per_cycle": (cold_obj or first_scf).get("ms_per_cycle", first_scf["ms_per_cycle_incl_first_use"]),
+                          "cold_iter_per_s": 1e3 / max((cold_obj or first_scf).get("ms_per_cycle", first_scf["ms_per_cycle_incl_first_use"]), 1e-9),
+                          "cold_cycles": (cold_obj or first_scf)["cycles"],
+                          "cold_note": "cycles of ONE kernel() on a fresh object (no purification plan: trace-correcting SP2, ~40 passes), "
+                                       "averaged over its own cycles, in a process whose libraries are loaded; `first_scf` is the same "
+                                       "call as this process's first (incl. first-use costs), `wall_clock` a whole cold process",
                           "workload_note": "default workload is benzene/cc-pVTZ since round 2 (round 1: cc-pVDZ): not comparable with BENCH_r01"},
                "roofline": roof, "roofline_more": more, "secondary": secondary, "e_tot": st["e_tot"],
-               "eri_seconds": stats["seconds_eri"], "setup_seconds": setup_s, "first_scf": first_scf, "scale_leg": scale_leg}
+               "eri_seconds": stats["seconds_eri"], "setup_seconds": setup_s, "first_scf": first_scf, "cold_object_scf": cold_obj, "scale_leg": scale_leg}
         if wall_children and (args.no_cpu_baseline or mol.nao > 300):
             out["wall_clock"] = {"gpu_kernel_seconds": wall_children[-1].get("kernel_seconds"), "gpu_breakdown": wall_children[-1].get("breakdown"),
                                  "gpu_first_process_on_box": wall_children[0], "cpu_total_seconds": None}

@@ -317,10 +317,20 @@ struct mi_ctx {
     int opt_tri_tiles = 1;   // block-diagonal tiles store triangular rows (0: the full-row layout of round 1); next mi_eri_prepare
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
+    int opt_jk_dpp = 1;      // per-tile reduce-scatters of the J/K kernel through DPP moves (0: ds_bpermute, the round-1/2 path)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
     int opt_ao_order = 1;    // tile AO order: 1 = angular-momentum major (all s, all p, ... ; tiles become class-homogeneous), 0 = caller's
     int opt_ket_cluster = 1; // kets ordered by (block pair of the store, shell) inside Schwarz-ordered clusters instead of by q alone
     int opt_xf_mlds = 0;     // transform kernel: stage the per-pair matrices in LDS when a quartet's blocks then fit this many KB (0: never; measured 1.3-3x SLOWER at 16-96)
+    int opt_rys_qpw_maxcomp = 256;   // Rys kernel: four quartets per wave for classes up to this many [e0|f0] components ...
+    double opt_rys_qpw_maxprim = 4.0; // ... whose quartets have at most about this many primitive quartets (0 components: off)
+    int opt_xf_qpw_max = 40;         // transform kernel: four quartets per wave up to this many spherical elements per quartet
+    // MiB of the [e0|f0] hand-over buffer between the Rys and the transform launches, and of each of the two buffers of the
+    // gradient.  Measured on ibuprofen/def2-TZVP (tools/eri_bench.py, ERI_OPTS): 12 / 48 / 256 / 1024 / 4096 MiB -> evaluation
+    // 0.53 / 0.38 / 0.353 / 0.353 / 0.339 s, gradient (2 x half of that) 3.9 / 2.1 / 1.23 / 1.14 / 1.11 s: few large launches beat
+    // many small ones (drain + ramp of latency-bound waves per launch); keeping a batch inside the Infinity Cache buys nothing
+    int opt_work_mb = 2048;
+    int opt_grad_work_mb = 1024;
     int opt_prim_lds = 0;    // Rys kernel: primitive-pair records of the quartet staged in LDS
     int opt_xcd_map = 1;     // ERI kernels: consecutive task chunks stay on one XCD (its L2 merges the pieces of a line)
     int ao_order = 0;        // order of the current shells[].ao / d_perm
@@ -552,6 +562,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_waves") c->opt_jk_waves = (int)value; // takes effect at the next mi_eri_prepare
     else if (k == "jk_nt") c->opt_jk_nt = (int)value;
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
+    else if (k == "jk_dpp") c->opt_jk_dpp = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
     else if (k == "jk_pair") c->opt_jk_pair = (int)value;
     else if (k == "sp2_persist") c->opt_sp2_persist = (int)value;
@@ -562,6 +573,11 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "ket_cluster") c->opt_ket_cluster = (int)value;   // takes effect at the next mi_eri_prepare
     else if (k == "xcd_map") c->opt_xcd_map = (int)value;
     else if (k == "prim_lds") c->opt_prim_lds = (int)value;
+    else if (k == "work_mb") c->opt_work_mb = (int)value;
+    else if (k == "grad_work_mb") c->opt_grad_work_mb = (int)value;
+    else if (k == "rys_qpw_maxcomp") c->opt_rys_qpw_maxcomp = (int)value;
+    else if (k == "rys_qpw_maxprim") c->opt_rys_qpw_maxprim = value;
+    else if (k == "xf_qpw_max") c->opt_xf_qpw_max = (int)value;
     else if (k == "xf_mlds") c->opt_xf_mlds = (int)value;
     else if (k == "eri_tpq") c->opt_eri_tpq = (int)value;
     else if (k == "tpq_maxprim") c->opt_tpq_maxprim = value;
@@ -1710,6 +1726,23 @@ static int launch_eri(mi_ctx *c, EriArgs &E, int nblocks, hipStream_t st)
             return 0;
         }
     }
+    // Round 3: four quartets per wave also for the MID classes when the contraction is shallow (uncontracted d / f shells: one
+    // primitive quartet keeps 2 n of 64 lanes busy in the root phase and 3 n in the recurrence phase of a one-quartet wave).
+    if (c->opt_rys_qpw_maxcomp > 0 && !E.diag && E.nroots <= 5 && E.ncomp > 18 && E.ncomp <= c->opt_rys_qpw_maxcomp && E.h_shared_np > 0.0 &&
+        E.h_shared_np * E.h_vary_max4 <= c->opt_rys_qpw_maxprim) {
+        EriArgs G = E;
+        G.PB = std::max(1, 16 / (3 * E.nroots));
+        const size_t shm = 4 * sizeof(double) * ((size_t)G.PB * G.nroots * 3 * G.tsz + (size_t)G.PB * 2 * G.nroots + (size_t)G.prim_lds * 8);
+        const dim3 grid(eri_grid((nblocks + 3) / 4, G.xcd));
+        const int per16 = (E.ncomp + 15) / 16;
+        if (shm <= 64 * 1024) {
+            if (per16 <= 4) hipLaunchKernelGGL((eri_rys_kernel<4, 16>), grid, dim3(64), shm, st, G);
+            else if (per16 <= 8) hipLaunchKernelGGL((eri_rys_kernel<8, 16>), grid, dim3(64), shm, st, G);
+            else hipLaunchKernelGGL((eri_rys_kernel<16, 16>), grid, dim3(64), shm, st, G);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
+    }
     size_t shm = sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots + (size_t)E.prim_lds * 8);
     if (perlane <= 1) hipLaunchKernelGGL((eri_rys_kernel<1, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
     else if (perlane <= 4) hipLaunchKernelGGL((eri_rys_kernel<4, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
@@ -1909,7 +1942,19 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
 
     lap("pairs + M matrices");
     // workspace for cartesian intermediates
-    const size_t WORK_DOUBLES = (size_t)32 << 20; // 256 MiB
+    // [e0|f0] blocks travel from the Rys launch to the transform launch through this buffer: small enough that a batch written by
+    // one launch is still in the 256 MiB Infinity Cache when the next reads it (`work_mb`)
+    // sized to what the molecule can need (atoms of the initial guess: a few MiB), at most `work_mb`
+    size_t WORK_DOUBLES = (size_t)8 << 17;
+    {
+        const size_t cap = (size_t)std::max(8, c->opt_work_mb) << 17;
+        for (int bc = 0; bc < NPC; bc++)
+            for (int kc = 0; kc <= bc; kc++) {
+                const PairClass &B = c->pc[bc], &Kc = c->pc[kc];
+                const double need = (double)B.recs.size() * (double)Kc.recs.size() * (double)B.ne * (double)Kc.ne;
+                WORK_DOUBLES = (size_t)std::min<double>((double)cap, std::max<double>((double)WORK_DOUBLES, need));
+            }
+    }
     double *d_work = nullptr;
     HIPCHK(hipMalloc(&d_work, sizeof(double) * WORK_DOUBLES));
     uint32_t *d_comp = nullptr;
@@ -2219,7 +2264,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             X.tiles = c->d_tiles; X.nao = c->nao; X.tri = c->tri;
             X.check_owner = nranks > 1; X.ni = E.ni; X.nj = E.nj; X.nk = E.nk; X.nl = E.nl;
             X.q_bra = E.q_bra; X.q_ket = E.q_ket; X.qtol = E.qtol; X.xcd = xcd_wave;
-            int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 22);
+            int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 24);
             size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
             {
                 const size_t with_m = shm2 + sizeof(double) * ((size_t)2 * X.nsab * X.ne + (size_t)2 * X.nscd * X.nf);
@@ -2230,7 +2275,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             // per-quartet latency chain better than MFMA tiles at 3-4 waves per SIMD (measured per class on ibuprofen/def2-TZVP)
             const bool xf_mfma = (mfma_worthwhile(X.nsab, X.nf, X.ne) || mfma_worthwhile(X.nsab, X.nscd, X.nf)) &&
                                  X.nsab * X.nscd >= c->opt_xf_mfma_min;
-            const bool xf_small = !xf_mfma && X.nsab * X.nscd <= 40 && shm2 * 4 <= 64 * 1024; // four quartets per wave
+            const bool xf_small = !xf_mfma && X.nsab * X.nscd <= c->opt_xf_qpw_max && shm2 * 4 <= 64 * 1024; // four quartets per wave
             if (shm2 > 64 * 1024)
                 HIPCHK(hipFuncSetAttribute(xf_mfma ? (const void *)eri_transform_scatter<true, 64> : (const void *)eri_transform_scatter<false, 64>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
@@ -2501,6 +2546,7 @@ struct JkArgs {
     int tri;                 // triangular rows in block-diagonal tiles (tile geometry)
     size_t pair_stride;      // jk_tiles_pair_kernel: doubles between the two padded densities / accumulator sets
     int pair_sync;           // barrier per tile between the two waves
+    int dpp;                 // per-tile reduce-scatters on the DPP path (reduce8_low) instead of ds_bpermute
 };
 
 __device__ inline double red_select_xor(double a, double b, bool hi, int mask)
@@ -2521,6 +2567,31 @@ __device__ inline double reduce8(const double v[8], int lane, int m2, int m1, in
 #pragma unroll
     for (int t = 0; t < 2; t++) b[t] = red_select_xor(a[t], a[t + 2], h1, m1);
     return red_select_xor(b[0], b[1], h0, m0);
+}
+
+// The same reduce-scatter over the three LOW lane bits (the 8 k-lanes of one i) on the DPP data path instead of the LDS crossbar
+// (ds_bpermute: two per double and a ~100-cycle round trip per dependent step, fully exposed at one wave per SIMD).  Step 1 pairs
+// lane b with 7 - b (row_half_mirror) instead of b ^ 4: both have opposite bit 2, which is all the first step needs; steps 2 and 3
+// (quad_perm) then combine disjoint groups exactly as the xor pattern does, so the lane -> element map is unchanged.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    union { double d; int w[2]; } u, r;
+    u.d = v;
+    r.w[0] = __builtin_amdgcn_update_dpp(0, u.w[0], CTRL, 0xF, 0xF, false);
+    r.w[1] = __builtin_amdgcn_update_dpp(0, u.w[1], CTRL, 0xF, 0xF, false);
+    return r.d;
+}
+__device__ __forceinline__ double reduce8_low(const double v[8], int lane)
+{
+    constexpr int HALF_MIRROR = 0x141, QP_XOR2 = 0x4E, QP_XOR1 = 0xB1;
+    double a[4], b[2];
+    const bool h2 = lane & 4, h1 = lane & 2, h0 = lane & 1;
+#pragma unroll
+    for (int t = 0; t < 4; t++) a[t] = (h2 ? v[t + 4] : v[t]) + dpp_move<HALF_MIRROR>(h2 ? v[t] : v[t + 4]);
+#pragma unroll
+    for (int t = 0; t < 2; t++) b[t] = (h1 ? a[t + 2] : a[t]) + dpp_move<QP_XOR2>(h1 ? a[t] : a[t + 2]);
+    return (h0 ? b[1] : b[0]) + dpp_move<QP_XOR1>(h0 ? b[0] : b[1]);
 }
 
 // One 16-byte chunk {T[i,j,k,2lp], T[i,j,k,2lp+1]} of the lane's sub-block.  DIJ / DKL: the tile lies on the I == J / K == L
@@ -2599,11 +2670,11 @@ __device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, 
     // (the same 0.24 GB written, then read), so the atomics stay.
     if (WITH_K) {
         atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik);
-        double r = reduce8(kil, lane, 4, 2, 1); // lane holds l = k
+        double r = A.dpp ? reduce8_low(kil, lane) : reduce8(kil, lane, 4, 2, 1); // lane holds l = k
         atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + L0 + k], r);
     }
     if (WITH_J) {
-        double r = reduce8(jij, lane, 4, 2, 1); // lane holds j = k
+        double r = A.dpp ? reduce8_low(jij, lane) : reduce8(jij, lane, 4, 2, 1); // lane holds j = k
         atomicAdd(&A.Jacc[(size_t)(I0 + i) * ld + J0 + k], r);
     }
 }
@@ -3003,7 +3074,7 @@ __global__ void finalize_jk_kernel(const double *Jacc, const double *Kacc, doubl
 static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
 {
     JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao,
-             c->n_jk_cached, c->tri, (size_t)c->ldp * c->ldp, 0};
+             c->n_jk_cached, c->tri, (size_t)c->ldp * c->ldp, 0, c->opt_jk_dpp};
     if (c->n_tiles == 0) return 0;
     dim3 g(A.nruns), b(64);
     // nontemporal loads only when the tensor cannot stay in the 256 MiB Infinity Cache between SCF cycles
@@ -3038,7 +3109,7 @@ extern "C" int mi_build_jk(mi_ctx *c, const double *d_D, int n_dm, double *d_J, 
             hipLaunchKernelGGL(pad_density_clear_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D + m * nn, c->d_Dpad + m * pp,
                                d_J ? c->d_Jacc + m * pp : nullptr, d_K ? c->d_Kacc + m * pp : nullptr, c->nao, c->ldp, c->d_iperm);
         JkArgs A{c->d_tiles, c->d_tile_off, c->d_tile_I, c->d_segs, c->d_wave_seg, c->n_jk_waves, c->d_Dpad, c->d_Jacc, c->d_Kacc, c->ldp, c->nao,
-                 c->n_jk_cached, c->tri, pp, 1};
+                 c->n_jk_cached, c->tri, pp, 1, c->opt_jk_dpp};
         dim3 g(A.nruns), b(128);
         // same cache policy as the single-density kernel: nontemporal stream + default-policy prefix for tensors beyond the
         // Infinity Cache (an all-default-policy stream of 4.9 GB made the launch time erratic: 1.65 ... 2.75 ms)
@@ -5372,7 +5443,17 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
     double *d_gcopies = nullptr;
     HIPCHK(hipMalloc(&d_gcopies, sizeof(double) * (size_t)GRAD_COPIES * natm3));
     HIPCHK(hipMemsetAsync(d_gcopies, 0, sizeof(double) * (size_t)GRAD_COPIES * natm3, st));
-    const size_t WORK_DOUBLES = (size_t)16 << 20; // per buffer (plus / minus)
+    size_t WORK_DOUBLES = (size_t)8 << 17; // per buffer (plus / minus): what the molecule can need, at most `grad_work_mb`
+    {
+        const size_t cap = (size_t)std::max(8, c->opt_grad_work_mb) << 17;
+        for (int bc = 0; bc < NPC; bc++)
+            for (int kc = 0; kc <= bc; kc++) {
+                const PairClass &B = c->pc[bc], &Kc = c->pc[kc];
+                const int ne_up = std::max(ne_of(B.la + 1, B.lb), ne_of(Kc.la + 1, Kc.lb));
+                const double need = (double)B.recs.size() * (double)Kc.recs.size() * (double)ne_up * (double)std::max(B.ne, Kc.ne);
+                WORK_DOUBLES = (size_t)std::min<double>((double)cap, std::max<double>((double)WORK_DOUBLES, need));
+            }
+    }
     double *d_wp = nullptr, *d_wm = nullptr;
     HIPCHK(hipMalloc(&d_wp, sizeof(double) * WORK_DOUBLES));
     HIPCHK(hipMalloc(&d_wm, sizeof(double) * WORK_DOUBLES));
@@ -5471,7 +5552,7 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 const bool dbg = getenv("MI355_DEBUG") != nullptr;
                 auto tc0 = std::chrono::steady_clock::now();
                 if (dbg) hipStreamSynchronize(st);
-                int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / Ep.ncomp), (int64_t)1 << 21);
+                int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / Ep.ncomp), (int64_t)1 << 23);
                 if (nranks > 1) per = std::min<int64_t>(per, std::max<int64_t>(1024, ntask / (8 * nranks)));
                 for (int64_t t0 = 0; t0 < ntask; t0 += per) {
                     if ((int)((batch_counter++) % nranks) != rank) continue; // batches dealt round-robin to ranks

@@ -671,6 +671,7 @@ class SCF:
         from . import sp2plan
         e = mo_e.cpu().numpy() if torch.is_tensor(mo_e) else np.asarray(mo_e)
         self._sp2_plan = None
+        self._sp2_plan_gen = getattr(self, "_sp2_plan_gen", 0) + 1
         if self.sp2_planned and self.eig_method == "sp2" and 0 < nocc < len(e) and self._sp2_plannable(len(e)):
             b = sp2plan.bounds_from_spectrum(e, nocc, self.sp2_inner_margin, self.sp2_outer_margin)
             self._sp2_plan = sp2plan.plan(*b)
@@ -887,6 +888,10 @@ class SCF:
                 and (self._sp2_plan is None or st.get("gnorm", 0.0) > self.sp2_plan_gnorm))
         if not (planned or cold):
             return None
+        if planned and self.graph_front:
+            out = self._front_graphed(st, nocc)
+            if out is not None:
+                return out
         fo = st["diis"].extrapolate()
         if planned:
             dmo, tr_dev = self._sp2_planned_async(fo, nocc)
@@ -899,6 +904,56 @@ class SCF:
         dm = (self._Linv.T @ dmo @ self._Linv).contiguous()
         return dict(fo=fo, dmo=dmo, dm=dm, tr=tr_dev, shape=shape, planned=planned)
 
+    # The planned head of a cycle is ~26 small launches (CDIIS combination, ~21 purification passes, 2-3 GEMMs) queued by the host
+    # between the wait for cycle k's scalars and the J/K launch of cycle k+1.  On a loaded host (measured on boxes of the pool:
+    # host time per cycle 0.26 ms or 0.6 ms from one run to the next) the device then waits for the host: 1.07 vs 1.25-1.5 ms per
+    # cycle.  Once the plan and the CDIIS history length are stable the head is captured ONCE as a HIP graph (torch.cuda.CUDAGraph:
+    # our ctypes launches go to torch's current stream, which is the capturing one) and replayed with a single launch call.
+    graph_front = True
+    _GRAPH_STABLE = 3   # cycles with an unchanged (plan, history length) before the head is captured
+
+    def _front_graphed(self, st, nocc):
+        """Replay (or capture) the planned head as a HIP graph; None = not available this cycle (the caller queues it eagerly)."""
+        diis = st["diis"]
+        m = min(diis.count, diis.space)
+        key = (id(diis), m, self._sp2_plan_len, getattr(self, "_sp2_plan_gen", 0), self._Linv.data_ptr())
+        g = self.__dict__.get("_fgraph")
+        if g is not None and g["key"] == key:
+            g["graph"].replay()
+            self._sp2_hist_shape = None
+            return dict(fo=g["fo"], dmo=g["dmo"], dm=g["dm"], tr=g["tr"], shape=g["shape"], planned=True)
+        seen = self.__dict__.get("_fgraph_seen")
+        if seen is None or seen[0] != key:
+            self._fgraph_seen = [key, 1]
+            return None
+        seen[1] += 1
+        if seen[1] < self._GRAPH_STABLE or m < diis.space:
+            return None
+        try:
+            def body():
+                fo = diis.extrapolate()
+                dmo, tr_dev = self._sp2_planned_async(fo, nocc)
+                shape, self._sp2_hist_shape = self._sp2_hist_shape, None
+                dm = torch.matmul(self._Linv.T @ dmo, self._Linv)
+                return fo, dmo, dm, tr_dev, shape
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                body()                       # warm-up outside the capture (library workspaces, lazy kernels)
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fo, dmo, dm, tr_dev, shape = body()
+            graph.replay()                   # the capture itself executes nothing
+            self._fgraph = dict(key=key, graph=graph, fo=fo, dmo=dmo, dm=dm, tr=tr_dev, shape=shape)
+            return dict(fo=fo, dmo=dmo, dm=dm, tr=tr_dev, shape=shape, planned=True)
+        except Exception as e:   # capture not possible on this stack: stay eager for good
+            self.graph_front = False
+            self._fgraph = None
+            self._log(4, f"HIP-graph capture of the SCF head failed ({e!r}); continuing with eager launches")
+            return None
+
     def _step(self, st, use_diis=True, want_mo=False):
         """One SCF cycle: CDIIS extrapolation -> occupied projector (SP2 or eigh) -> density -> J/K ->
         energy, orbital gradient.  This is the unit bench.py times ("SCF iteration").  With `pipeline` the first three
@@ -907,11 +962,16 @@ class SCF:
         front = st.pop("front", None)
         if want_mo or not use_diis:
             front = None                                 # final cycle: plain diagonalisation of the last Fock matrix
+        paths = self.__dict__.setdefault("path_counts", {})   # diagnostics: purification path per cycle (tools/host_busy.py)
+
+        def took(name):
+            paths[name] = paths.get(name, 0) + 1
         tr_dev, hist_shape = None, None
         self._sp2_planned_pass = False
         if front is not None:
             fo, dmo, tr_dev, hist_shape, dm = front["fo"], front["dmo"], front["tr"], front["shape"], front["dm"]
             self._sp2_planned_pass = bool(front.get("planned", True))
+            took("front_planned" if self._sp2_planned_pass else "front_cold")
             planned_ok = True
             st.pop("mo_e", None)
         else:
@@ -938,11 +998,13 @@ class SCF:
             if planned_ok and self._sp2_plan is not None and settled and not st.get("_redo"):
                 dmo, tr_dev = self._sp2_planned_async(fo, nocc)
                 self._sp2_planned_pass = True
+                took("planned_nofront")
             elif planned_ok and self._sp2_plan is not None and not settled:
                 # a plan exists (seeded by an earlier SCF of this object) but this SCF is still far from its solution -- e.g.
                 # kernel() from the atomic guess again: the spectrum is not the planned one yet (measured: three redo cycles,
                 # each a diagonalisation and a second Fock build).  Checked purification until the SCF has settled.
                 dmo = self._density_sp2(fo, nocc, orth=True)
+                took("checked_unsettled_with_plan")
             elif early and st.get("gnorm", 0.0) > self.sp2_plan_gnorm:
                 if self.cold_pipeline and self._sp2_validated and not st.get("_redo") and n <= self.sp2_fused_max and self.sp2_fused:
                     # optimistic: last count + a generous margin, validated with the cycle's scalars (no host sync here)
@@ -955,6 +1017,7 @@ class SCF:
                     dmo = self._density_sp2(fo, nocc, orth=True)
             elif early and self._sp2_validated and not st.get("_redo"):
                 dmo, tr_dev = self._sp2_fused_async(fo, nocc)     # settled, but no plan on this object yet (see sp2_plan_inloop)
+                took("optimistic_noplan")
             elif early:
                 dmo = self._density_sp2(fo, nocc, orth=True)
             elif planned_ok:
@@ -969,6 +1032,7 @@ class SCF:
                 dmo = self._density_sp2(fo, nocc, orth=True)
             hist_shape, self._sp2_hist_shape = getattr(self, "_sp2_hist_shape", None), None
             if dmo is None:
+                took("eigh")
                 e, c = torch.linalg.eigh(fo)
                 co = c[:, :nocc]
                 dmo = 2.0 * co @ co.T

@@ -166,8 +166,9 @@ def test_benzene_b3lyp_frequencies_ir_and_thermo_against_literature():
 def test_water_hessian_matches_second_differences_of_the_oracle_energy():
     """Parity (not self-consistency): every element of the semi-numerical HIP Hessian of H2O RHF/6-31G against second
     differences of the CPU ORACLE's SCF energy (McMurchie-Davidson integrals, numpy SCF: a different code path end to end).
-    H_ij = [E(+i+j) - E(+i-j) - E(-i+j) + E(-i-j)] / 4 h^2 with h = 0.02 Bohr (truncation ~h^2 E'''' / 6 ~ 1e-5, energy noise
-    1e-12 / 4 h^2 ~ 1e-9), diagonal by the three-point formula; tolerance 5e-5 Hartree/Bohr^2 on elements of order 0.1-0.7."""
+    H_ij = [E(+i+j) - E(+i-j) - E(-i+j) + E(-i-j)] / 4 h^2 with h = 0.005 Bohr (truncation ~h^2 E'''' / 6 ~ 2e-5 -- h = 0.02 gave
+    3e-4 -- energy noise 1e-12 / h^2 ~ 4e-8), diagonal by the three-point formula; tolerance 5e-5 Hartree/Bohr^2 on elements of
+    order 0.1-0.7."""
     from pyscf import gto, scf, hessian
     from oracle import oracle as orc
     mol = gto.Mole()
@@ -180,7 +181,7 @@ def test_water_hessian_matches_second_differences_of_the_oracle_energy():
     n = mol.natm
     H = hess.transpose(0, 2, 1, 3).reshape(3 * n, 3 * n)
     R = mol.atom_coords().ravel()
-    h = 0.02
+    h = 0.005
 
     def e_orc(dx):
         m2 = mol.set_geom_((R + dx).reshape(-1, 3), unit="Bohr", inplace=False)

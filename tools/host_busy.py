@@ -29,6 +29,7 @@ for _ in range(steps):
 torch.cuda.synchronize()
 tot = time.perf_counter() - t0
 torch.cuda.Event.synchronize = orig
+print("graph", mf.__dict__.get("_fgraph") is not None, "paths", getattr(mf, "path_counts", None), "plan", None if mf._sp2_plan is None else (mf._sp2_plan.shape, mf._sp2_plan_len), "redo", getattr(mf, "n_redo", 0))
 print(json.dumps(dict(basis=basis, steps=steps, ms_per_cycle=round(tot / steps * 1e3, 4), host_wait_ms=round(wait[0] / steps * 1e3, 4),
                       host_busy_ms=round((tot - wait[0]) / steps * 1e3, 4), cpus=os.cpu_count(),
                       cpu_model=[l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][:1])))
