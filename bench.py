@@ -295,6 +295,8 @@ def main():
     # host-side set-up gaps run 4-8 % slower than the rest (tools/jk_drift.py: 0.82-0.85 ms, then 0.784 ms flat).  With the
     # driver's W = 5, K = 20 the whole timed region is 25 ms, i.e. it would sit inside that ramp.  A fixed count (same on every
     # rank: each cycle holds a collective); direct-mode workloads (seconds per cycle) keep the minimum.
+    from mi355scf import engine as _engine_mod
+    _engine_mod.wait_warm()    # the library warm-up thread (rocSOLVER initialisation, ~0.3 s) must not share the interpreter with the timed loop
     SETTLE = 4 if mf._stream_groups > 1 else 60
     for _ in range(SETTLE):
         mf._step(st)

@@ -331,6 +331,7 @@ struct mi_ctx {
     // many small ones (drain + ramp of latency-bound waves per launch); keeping a batch inside the Infinity Cache buys nothing
     int opt_work_mb = 2048;
     int opt_grad_work_mb = 1024;
+    int opt_task_table = 1;  // wave-per-quartet kernels read (bra, ket) of a task from a table written once per class pair
     int opt_prim_lds = 0;    // Rys kernel: primitive-pair records of the quartet staged in LDS
     int opt_xcd_map = 1;     // ERI kernels: consecutive task chunks stay on one XCD (its L2 merges the pieces of a line)
     int ao_order = 0;        // order of the current shells[].ao / d_perm
@@ -573,6 +574,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "ket_cluster") c->opt_ket_cluster = (int)value;   // takes effect at the next mi_eri_prepare
     else if (k == "xcd_map") c->opt_xcd_map = (int)value;
     else if (k == "prim_lds") c->opt_prim_lds = (int)value;
+    else if (k == "task_table") c->opt_task_table = (int)value;
     else if (k == "work_mb") c->opt_work_mb = (int)value;
     else if (k == "grad_work_mb") c->opt_grad_work_mb = (int)value;
     else if (k == "rys_qpw_maxcomp") c->opt_rys_qpw_maxcomp = (int)value;
@@ -776,6 +778,7 @@ extern "C" int mi_int1e(mi_ctx *c, double *d_S, double *d_T, double *d_V, double
 //            T[n][m], n <= la+lb, m <= lc+ld  -> LDS
 //   phase C  lanes <-> output components (e,f): sum over slots of Tx*Ty*Tz, accumulators in VGPRs
 // =================================================================================================
+struct TaskIdx { int ib, ik; };   // (bra, ket) of one task (get_task)
 struct EriArgs {
     const PairRec *bra, *ket;
     const double *prim;
@@ -798,6 +801,7 @@ struct EriArgs {
     double dtol, hyb;
     // host side only (kernel choice): primitive-pair statistics of the shared (bra) and the varying (ket) pair list
     double h_shared_np, h_vary_mean, h_vary_max4;
+    const TaskIdx *tasks;    // non-null: (bra, ket) per task, precomputed (get_task)
     int prim_lds;            // > 0: stage the primitive-pair records of the quartet in LDS (room for this many records per quartet)
     double qtol;             // > 0: skip tasks with q_bra q_ket < qtol (kets of a surviving cluster that fail the Schwarz test themselves)
     unsigned xcd;            // > 0: XCD-aware block map with chunks of this many blocks (xcd_block), grid rounded up to 8 * xcd
@@ -844,6 +848,24 @@ __device__ inline void find_task(const int64_t *prefix, int nbra, int64_t t, int
     ik = (int)(t - prefix[lo]);
 }
 
+// (bra, ket) of every task of a class pair, written once (fill_tasks_kernel) when several launches walk the same task list --
+// the Rys and transform launches of the evaluation, the 3 permutations x 3 launches of the gradient: one coalesced 8-byte load
+// per quartet instead of the two or three DEPENDENT global loads of find_task (~2 us of a ~10 us quartet in those latency-
+// bound kernels).
+__device__ inline void get_task(const TaskIdx *tasks, const int64_t *prefix, int nbra, int64_t t, int &ib, int &ik)
+{
+    if (tasks) { const TaskIdx q = tasks[t]; ib = q.ib; ik = q.ik; }
+    else find_task(prefix, nbra, t, ib, ik);
+}
+__global__ __launch_bounds__(256) void fill_tasks_kernel(const int64_t *prefix, int nbra, int64_t ntask, TaskIdx *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntask) return;
+    int ib, ik;
+    find_task(prefix, nbra, t, ib, ik);
+    out[t] = TaskIdx{ib, ik};
+}
+
 // Does any AO quadruple of the shell quartet land in a tile that is resident on this rank?  (<= 16 block
 // combinations; every symmetry image of a quadruple maps to the same canonical tile.)
 __device__ inline bool quartet_has_resident_tile(const int32_t *table, int ao_i, int ni, int ao_j, int nj, int ao_k, int nk,
@@ -881,7 +903,7 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
     const int64_t task = A.t0 + (live ? tl : 0);
     int ib, ik;
     if (A.diag) { ib = (int)task; ik = ib; }
-    else find_task(A.prefix, A.nbra, task, ib, ik);
+    else get_task(A.tasks, A.prefix, A.nbra, task, ib, ik);
     if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
     if (A.qtol > 0.0 && A.q_bra[ib] * A.q_ket[ik] < A.qtol) { if (QPW == 1) return; live = false; }
@@ -1065,6 +1087,7 @@ struct XfArgs {
     const double *q_bra, *q_ket; // with qtol > 0: the same per-task Schwarz rejection as the Rys kernel made
     double qtol;
     unsigned xcd;            // XCD-aware block map (xcd_block)
+    const TaskIdx *tasks;    // non-null: (bra, ket) per task, precomputed (get_task)
     int m_lds;               // 1: the two per-pair transformation matrices are staged in LDS with the E0 block (one memory round trip
                              // for all operands; a global load per k step made the products a chain of dependent round trips)
 };
@@ -1122,7 +1145,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const int64_t tl = (int64_t)xcd_block(blockIdx.x, A.xcd) * QPW + grp;
     bool live = tl < A.ntask;
     int ib, ik;
-    find_task(A.prefix, A.nbra, A.t0 + (live ? tl : 0), ib, ik);
+    get_task(A.tasks, A.prefix, A.nbra, A.t0 + (live ? tl : 0), ib, ik);
     const PairRec ab = A.bra[ib], cd = A.ket[ik];
     if (A.qtol > 0.0 && A.q_bra[ib] * A.q_ket[ik] < A.qtol) live = false;
     if (A.check_owner)
@@ -1782,6 +1805,7 @@ static int launch_eri_tpq_t(const TpqArgs &Q, hipStream_t st)
     return 1;
 }
 
+static bool tpq_has_class(int la, int lb, int lc, int ld);
 static int launch_eri_tpq(int la, int lb, int lc, int ld, const TpqArgs &Q, hipStream_t st)
 {
     const int key = ((la * 4 + lb) * 4 + lc) * 4 + ld;
@@ -1795,6 +1819,13 @@ static int launch_eri_tpq(int la, int lb, int lc, int ld, const TpqArgs &Q, hipS
     default: return 0;
     }
 #undef TPQ_CASE
+}
+static bool tpq_has_class(int la, int lb, int lc, int ld)
+{
+    static const int keys[][4] = {{0,0,0,0},{1,0,0,0},{1,0,1,0},{1,1,0,0},{1,1,1,0},{2,0,0,0},{2,0,1,0},{2,0,1,1},{2,0,2,0},{2,1,0,0},
+                                  {2,1,1,0},{2,2,0,0},{3,0,0,0},{3,0,1,0},{3,0,2,0},{3,1,0,0},{3,2,0,0},{2,1,2,0},{2,2,1,0},{3,3,0,0}};
+    for (const auto &k : keys) if (k[0] == la && k[1] == lb && k[2] == lc && k[3] == ld) return true;
+    return false;
 }
 
 // Sharding plan of the resident tile store: enumerate the (J,K,L) runs that survive the block-pair
@@ -2228,6 +2259,8 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     int64_t nquart = 0;
     int64_t *d_prefix = nullptr;
     size_t prefix_cap = 0;
+    TaskIdx *d_tasks = nullptr;
+    size_t tasks_cap = 0;
     for (int bc = 0; bc < NPC; bc++)
         for (int kc = 0; kc <= bc; kc++) {
             PairClass &B = c->pc[bc], &Kc = c->pc[kc];
@@ -2244,6 +2277,17 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
             EriArgs E{};
             setup_eri_dims(E, B.la, B.lb, Kc.la, Kc.lb);
+            const bool tpq_class = c->opt_eri_tpq && B.mean_np * Kc.mean_np <= c->opt_tpq_maxprim && ntask >= 32768 &&
+                                   tpq_has_class(B.la, B.lb, Kc.la, Kc.lb);
+            if (c->opt_task_table && !tpq_class && ntask >= 65536) {   // the wave-per-quartet pair walks the task list twice
+                if ((size_t)ntask > tasks_cap) {
+                    if (d_tasks) hipFree(d_tasks);
+                    tasks_cap = (size_t)ntask + (size_t)ntask / 4;
+                    HIPCHK(hipMalloc(&d_tasks, sizeof(TaskIdx) * tasks_cap));
+                }
+                hipLaunchKernelGGL(fill_tasks_kernel, dim3((unsigned)((ntask + 255) / 256)), dim3(256), 0, st, d_prefix, (int)B.recs.size(), ntask, d_tasks);
+                E.tasks = d_tasks;
+            }
             std::vector<uint32_t> comp;
             build_comp_table(B.la, B.lb, Kc.la, Kc.lb, comp);
             HIPCHK(hipMemcpyAsync(d_comp, comp.data(), sizeof(uint32_t) * comp.size(), hipMemcpyHostToDevice, st));
@@ -2263,7 +2307,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             X.work = d_work; X.ncomp = E.ncomp; X.tile_table = c->d_tile_table; X.tile_off = c->d_tile_off;
             X.tiles = c->d_tiles; X.nao = c->nao; X.tri = c->tri;
             X.check_owner = nranks > 1; X.ni = E.ni; X.nj = E.nj; X.nk = E.nk; X.nl = E.nl;
-            X.q_bra = E.q_bra; X.q_ket = E.q_ket; X.qtol = E.qtol; X.xcd = xcd_wave;
+            X.q_bra = E.q_bra; X.q_ket = E.q_ket; X.qtol = E.qtol; X.xcd = xcd_wave; X.tasks = E.tasks;
             int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / E.ncomp), (int64_t)1 << 24);
             size_t shm2 = sizeof(double) * ((size_t)X.ne * X.nf + (size_t)X.nsab * X.nf);
             {
@@ -2329,6 +2373,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     HIPCHK(hipStreamSynchronize(st));
     lap("quartet evaluation");
     if (d_prefix) hipFree(d_prefix);
+    if (d_tasks) hipFree(d_tasks);
     hipFree(d_work);
     hipFree(d_comp);
     lap("free scratch");
@@ -4896,6 +4941,7 @@ struct GradXfArgs {
     int inv_from_second; // translational invariance: 1: the skipped shell is dp.sh_j, 0: it is cd.sh_i
     int natm3;           // grad points to GRAD_COPIES private copies of [natm*3] (atomic contention relief)
     int64_t nbatch;      // tasks in this launch
+    const TaskIdx *tasks; // non-null: (bra, ket) per task, precomputed (get_task)
     const double *q_bra, *q_ket, *dmax; // same screening as EriArgs (the Rys kernel left these quartets' blocks unwritten)
     int nbas_d;
     double dtol;
@@ -4926,7 +4972,7 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
     double *G = E0m + (has_m ? (size_t)A.ne_m * nf : 0);      // [nsab][nscd]
     double *Y = G + (size_t)nsab * A.nscd;                    // [nsab][nf]
     int ib = 0, ik = 0;
-    if (in_batch) find_task(A.prefix, A.nbra, A.t0 + tl, ib, ik);
+    if (in_batch) get_task(A.tasks, A.prefix, A.nbra, A.t0 + tl, ib, ik);
     const bool same_pair = A.same_class && ib == ik;
     if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec dp = A.dplus[ib], cd = A.ket[ik];
@@ -5462,6 +5508,8 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
     HIPCHK(hipMalloc(&d_comp_m, sizeof(uint32_t) * 16384));
     int64_t *d_prefix = nullptr;
     size_t prefix_cap = 0;
+    TaskIdx *d_tasks = nullptr;
+    size_t tasks_cap = 0;
     const double tol = c->tol;
     int64_t batch_counter = 0;
     for (int bc = 0; bc < NPC; bc++)
@@ -5477,6 +5525,16 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 HIPCHK(hipMalloc(&d_prefix, sizeof(int64_t) * prefix_cap));
             }
             HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
+            const TaskIdx *tasks_dev = nullptr;
+            if (c->opt_task_table && ntask >= 65536) {   // up to 3 permutations x 3 launches walk this task list
+                if ((size_t)ntask > tasks_cap) {
+                    if (d_tasks) hipFree(d_tasks);
+                    tasks_cap = (size_t)ntask + (size_t)ntask / 4;
+                    HIPCHK(hipMalloc(&d_tasks, sizeof(TaskIdx) * tasks_cap));
+                }
+                hipLaunchKernelGGL(fill_tasks_kernel, dim3((unsigned)((ntask + 255) / 256)), dim3(256), 0, st, d_prefix, (int)B.recs.size(), ntask, d_tasks);
+                tasks_dev = d_tasks;
+            }
             HIPCHK(hipStreamSynchronize(st));
             // perm 0 (derivative on P.sh_i, the costliest: highest l) is skipped: sum of the four forces = 0
             for (int perm = 1; perm < 4; perm++) {
@@ -5533,6 +5591,7 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                     Em.bra = Dc.d_g_recs[orient][1]; Em.ket = Oc.d_recs; Em.prim = c->d_prim; Em.prefix = d_prefix; Em.nbra = Ep.nbra;
                     Em.comp = d_comp_m; Em.work = d_wm; Em.rys = c->rys; Em.diag = 0; Em.swap = Ep.swap;
                 }
+                Ep.tasks = Em.tasks = tasks_dev;
                 Ep.prim_lds = Em.prim_lds = (c->opt_prim_lds && B.max_np + Kc.max_np <= 160) ? B.max_np + Kc.max_np : 0;
                 Ep.h_shared_np = B.mean_np; Ep.h_vary_mean = Kc.mean_np; Ep.h_vary_max4 = Kc.max4_np;
                 Em.h_shared_np = B.mean_np; Em.h_vary_mean = Kc.mean_np; Em.h_vary_max4 = Kc.max4_np;
@@ -5547,6 +5606,7 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 X.work_p = d_wp; X.work_m = d_wm; X.ncomp_p = Ep.ncomp; X.ncomp_m = has_m ? Em.ncomp : 0;
                 X.D = c->d_Dpad; X.Dm = d_Mpad; X.ld = c->ldp; X.hyb = hyb; X.shell_atom = d_shell_atom; X.grad = d_gcopies; X.natm3 = natm3;
                 X.inv_from_second = swap ? 0 : 1;
+                X.tasks = tasks_dev;
                 size_t shm = sizeof(double) * ((size_t)X.ne_p * X.nf + (size_t)X.ne_m * X.nf + (size_t)X.ns1 * X.ns2 * (X.nf + X.nscd));
                 if (shm > 160 * 1024) return fail("gradient contraction needs %zu bytes of LDS", shm);
                 const bool dbg = getenv("MI355_DEBUG") != nullptr;
@@ -5594,6 +5654,7 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 std::chrono::duration<double>(tg1 - tg0).count(),
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count());
     if (d_prefix) hipFree(d_prefix);
+    if (d_tasks) hipFree(d_tasks);
     hipFree(d_wp); hipFree(d_wm); hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_shell_atom);
     if (d_dmax) hipFree(d_dmax);
     if (d_Mpad) hipFree(d_Mpad);

@@ -601,6 +601,15 @@ def _warm_libraries(device, n=32, nocc=24):
     atexit.register(lambda: t.join(timeout=10.0))   # never tear the interpreter down under a HIP call of the helper thread
 
 
+def wait_warm(timeout=30.0):
+    """Block until the library warm-up thread (`_warm_libraries`) has finished.  Measurement code calls this before a timed
+    region: the helper thread initialises rocSOLVER for ~0.3 s after the first Engine is created and competes with the SCF
+    loop for the interpreter lock while it runs (seen as a doubled host time per cycle in bench.py)."""
+    t = _WARM.get("thread")
+    if t is not None and t.is_alive():
+        t.join(timeout)
+
+
 _ENGINES = {}
 
 
