@@ -331,6 +331,7 @@ struct mi_ctx {
     // many small ones (drain + ramp of latency-bound waves per launch); keeping a batch inside the Infinity Cache buys nothing
     int opt_work_mb = 2048;
     int opt_grad_work_mb = 1024;
+    int opt_eri_fused = 0;   // mid / high classes: fused Rys + transform + scatter kernel (1) instead of the two-launch pair with its hand-over buffer -- measured SLOWER (0.273 vs 0.245 s): default off
     int opt_task_table = 1;  // wave-per-quartet kernels read (bra, ket) of a task from a table written once per class pair
     int opt_prim_lds = 0;    // Rys kernel: primitive-pair records of the quartet staged in LDS
     int opt_xcd_map = 1;     // ERI kernels: consecutive task chunks stay on one XCD (its L2 merges the pieces of a line)
@@ -575,6 +576,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "xcd_map") c->opt_xcd_map = (int)value;
     else if (k == "prim_lds") c->opt_prim_lds = (int)value;
     else if (k == "task_table") c->opt_task_table = (int)value;
+    else if (k == "eri_fused") c->opt_eri_fused = (int)value;
     else if (k == "work_mb") c->opt_work_mb = (int)value;
     else if (k == "grad_work_mb") c->opt_grad_work_mb = (int)value;
     else if (k == "rys_qpw_maxcomp") c->opt_rys_qpw_maxcomp = (int)value;
@@ -1020,6 +1022,85 @@ __global__ __launch_bounds__(64) void eri_rys_kernel(EriArgs A)
     }
 }
 
+// The Rys phases of eri_rys_kernel for ONE quartet on ONE wave with the contracted [e0|f0] block written to LDS instead of the
+// hand-over buffer: the first half of the fused evaluation kernel (eri_fused_kernel).  `scratch` holds the recurrence tables and
+// the roots / weights of a batch ([PB n][3][tsz] + [PB][2 n] doubles), `out` the block ([ncomp] doubles, both in LDS).
+template <int MAXC>
+__device__ __forceinline__ void rys_core(const EriArgs &A, const PairRec &ab, const PairRec &cd, const int lane, double *scratch, double *out)
+{
+    const int n = A.nroots, tsz = A.tsz, M1 = A.mmax + 1;
+    const int ncd = cd.nprim, nPQ = ab.nprim * ncd;
+    const int PB = A.PB;
+    double *T0 = scratch;                              // [PB*n][3][tsz]
+    double *rw = scratch + (size_t)PB * n * 3 * tsz;   // [PB][2n]
+    const double *prim_b = A.prim + (size_t)ab.prim_off * 8, *prim_k = A.prim + (size_t)cd.prim_off * 8;
+    for (int c0 = 0; c0 < A.ncomp; c0 += 64 * MAXC) {
+        double acc[MAXC];
+        uint32_t idx[MAXC];
+#pragma unroll
+        for (int ci = 0; ci < MAXC; ci++) {
+            acc[ci] = 0.0;
+            const int c = c0 + ci * 64 + lane;
+            idx[ci] = (c < A.ncomp) ? A.comp[c] : 0xFFFFFFFFu;
+        }
+        for (int pq0 = 0; pq0 < nPQ; pq0 += PB) {
+            const int npq = min(PB, nPQ - pq0);
+            if (lane < npq * 2 * n) {                  // roots and weights
+                const int pql = lane / (2 * n), f = lane - pql * 2 * n;
+                const int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
+                const double *b = prim_b + (size_t)ip * 8, *k = prim_k + (size_t)jp * 8;
+                const double p = b[0], q = k[0];
+                const double dx = b[1] - k[1], dy = b[2] - k[2], dz = b[3] - k[3];
+                rw[pql * 2 * n + f] = rys_eval(A.rys, n, f, p * q / (p + q) * (dx * dx + dy * dy + dz * dz));
+            }
+            __syncthreads();
+            if (lane < npq * n * 3) {                  // 2-D recurrence tables
+                const int pql = lane / (3 * n), rem = lane - pql * 3 * n, r = rem / 3, d = rem - r * 3;
+                const int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
+                const double *b = prim_b + (size_t)ip * 8, *k = prim_k + (size_t)jp * 8;
+                const double p = b[0], q = k[0], pq1 = 1.0 / (p + q);
+                const double u = rw[pql * 2 * n + r];
+                const double PQd = b[1 + d] - k[1 + d];
+                const double b00 = 0.5 * u * pq1, b10 = 0.5 / p * (1.0 - u * q * pq1), b01 = 0.5 / q * (1.0 - u * p * pq1);
+                const double c00 = b[4 + d] - u * q * pq1 * PQd, c01 = k[4 + d] + u * p * pq1 * PQd;
+                double *T = T0 + ((size_t)(pql * n + r) * 3 + d) * tsz;
+                double t00 = 1.0;
+                if (d == 2) t00 = rw[pql * 2 * n + n + r] * b[7] * k[7] * 34.986836655249725 /* 2 pi^2.5 */ * pq1 * sqrt(p + q) / (p * q);
+                T[0] = t00;
+                double tm = 0.0, tc = t00;
+                for (int i = 0; i < A.nmax; i++) {
+                    const double tn = c00 * tc + i * b10 * tm;
+                    T[(i + 1) * M1] = tn;
+                    tm = tc; tc = tn;
+                }
+                for (int m = 0; m < A.mmax; m++)
+                    for (int i = 0; i <= A.nmax; i++) {
+                        double v = c01 * T[i * M1 + m];
+                        if (m > 0) v += m * b01 * T[i * M1 + m - 1];
+                        if (i > 0) v += i * b00 * T[(i - 1) * M1 + m];
+                        T[i * M1 + m + 1] = v;
+                    }
+            }
+            __syncthreads();
+            const int nslot = npq * n;                 // component products
+            for (int s_ = 0; s_ < nslot; s_++) {
+                const double *Tx = T0 + (size_t)s_ * 3 * tsz, *Ty = Tx + tsz, *Tz = Ty + tsz;
+#pragma unroll
+                for (int ci = 0; ci < MAXC; ci++) {
+                    const uint32_t w = idx[ci];
+                    if (w != 0xFFFFFFFFu) acc[ci] += Tx[w & 1023u] * Ty[(w >> 10) & 1023u] * Tz[(w >> 20) & 1023u];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ci = 0; ci < MAXC; ci++) {
+            const int c = c0 + ci * 64 + lane;
+            if (c < A.ncomp) out[c] = acc[ci];
+        }
+    }
+}
+
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // One 16x16 tile of C = A B on a single wave with v_mfma_f64_16x16x4_f64 (used by the per-quartet transformation
@@ -1135,8 +1216,12 @@ __device__ inline void put_tile_at(const XfArgs &A, int64_t base, int i, int j, 
     if (e >= 0) A.tiles[base + e] = w * v;
 }
 
-template <bool MFMA, int GSZ>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void eri_transform_scatter(XfArgs A)
+// FMAXC = 0: the [e0|f0] block comes from the hand-over buffer (A.work) of a preceding eri_rys_kernel launch.
+// FMAXC > 0 (GSZ = 64 only): FUSED evaluation -- the Rys phases (rys_core<FMAXC>, arguments *R) run first in this wave and leave
+// the block in LDS: no hand-over buffer (51.8 of the 139.8 GB written by an evaluation of ibuprofen/def2-TZVP), one launch
+// and one task look-up per quartet instead of two.
+template <bool MFMA, int GSZ, int FMAXC>
+__device__ __forceinline__ void xf_body(const XfArgs &A, const EriArgs *R)
 {
     extern __shared__ double lds_all[];
     constexpr int QPW = 64 / GSZ;
@@ -1151,7 +1236,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     if (A.check_owner)
         live = quartet_has_resident_tile(A.tile_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane, GSZ, grp) && live;
     if (QPW == 1 && !live) return;
-    const double *E0g = A.work + (size_t)tl * A.ncomp;
+    const double *E0g = FMAXC > 0 ? nullptr : A.work + (size_t)tl * A.ncomp;
     const size_t lds_m = A.m_lds ? (size_t)2 * A.nsab * A.ne + (size_t)2 * A.nscd * A.nf : 0;
     double *E0 = lds_all + (size_t)grp * ((size_t)A.ne * A.nf + (size_t)A.nsab * A.nf + lds_m); // [ne][nf]
     double *X = E0 + A.ne * A.nf;                                                       // [nsab][nf]
@@ -1168,7 +1253,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         Mab = ML; Mcd = ML + na;
     }
     const double *MabT = Mab + A.nsab * A.ne, *McdT = Mcd + A.nscd * A.nf;   // [e][r], [f][c]
-    if (live)
+    if (FMAXC > 0) rys_core<(FMAXC > 0 ? FMAXC : 1)>(*R, ab, cd, lane, X /* tables over the not yet used X block */, E0);
+    else if (live)
         for (int c = lane; c < A.ne * A.nf; c += GSZ) E0[c] = E0g[c];
     // symmetry images: role of (a0,a1,a2,a3) = (ab.i, ab.j, cd.i, cd.j) in (i,j,k,l); bit 0 swaps the bra pair, bit 1 the ket
     // pair, bit 2 exchanges bra and ket.  Which images can land in a canonical tile (I >= J, K >= L) at all is decided once per
@@ -1307,6 +1393,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
         }
     }
+}
+
+template <bool MFMA, int GSZ>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void eri_transform_scatter(XfArgs A)
+{
+    xf_body<MFMA, GSZ, 0>(A, nullptr);
+}
+
+// Fused evaluation of the mid / high classes: Rys quadrature, HRR + cart->sph products and the scatter of one quartet in ONE wave
+// and ONE launch (round 3).  FMAXC = [e0|f0] components per lane kept in registers during the primitive loop.
+struct FusedArgs { XfArgs X; EriArgs R; };
+template <bool MFMA, int FMAXC>
+__global__ __launch_bounds__(64) void eri_fused_kernel(FusedArgs F)
+{
+    xf_body<MFMA, 64, FMAXC>(F.X, &F.R);
 }
 
 // =================================================================================================
@@ -2345,6 +2446,46 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                         hipStreamSynchronize(st);
                         t_rys = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
                         fprintf(stderr, "[mi355] eri class (%d%d|%d%d): %ld quartets, thread-per-quartet fused kernel %.4f s (%.2f ns/q)\n", B.la, B.lb,
+                                Kc.la, Kc.lb, (long)ntask, t_rys, t_rys / ntask * 1e9);
+                    }
+                    continue;
+                }
+            }
+            if (c->opt_eri_fused && !E.diag) {
+                // one fused launch per (at most 2^30) tasks: no hand-over buffer, so no batching by its size
+                FusedArgs F;
+                F.R = E; F.X = X;
+                F.R.PB = std::max(1, std::min(E.PB, B.max_np * Kc.max_np));   // uncontracted d / f shells: one primitive quartet per batch
+                F.R.prim_lds = 0; F.R.own_table = nullptr; F.R.qtol = 0.0; F.R.dmax = nullptr;   // (the transform half screens: check_owner, qtol)
+                F.X.m_lds = 0;
+                const size_t scratch = (size_t)F.R.PB * E.nroots * 3 * E.tsz + (size_t)F.R.PB * 2 * E.nroots;
+                const size_t shmf = sizeof(double) * ((size_t)X.ne * X.nf + std::max((size_t)X.nsab * X.nf, scratch));
+                if (shmf <= 160 * 1024) {
+                    const int perlane = (E.ncomp + 63) / 64;
+                    auto ta = std::chrono::steady_clock::now();
+                    if (dbg) hipStreamSynchronize(st);
+                    for (int64_t t0 = 0; t0 < ntask; t0 += (int64_t)1 << 30) {
+                        const int64_t nb = std::min<int64_t>((int64_t)1 << 30, ntask - t0);
+                        F.X.t0 = t0; F.X.ntask = nb; F.X.xcd = nb >= 2048 ? xcd_wave : 0u;
+                        const dim3 grid(eri_grid(nb, F.X.xcd));
+#define FUSED_LAUNCH(MF, MC)                                                                                                               \
+    do {                                                                                                                                   \
+        if (shmf > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)eri_fused_kernel<MF, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmf)); \
+        hipLaunchKernelGGL((eri_fused_kernel<MF, MC>), grid, dim3(64), shmf, st, F);                                                        \
+    } while (0)
+                        if (xf_mfma) {
+                            if (perlane <= 4) FUSED_LAUNCH(true, 4); else if (perlane <= 16) FUSED_LAUNCH(true, 16); else FUSED_LAUNCH(true, 32);
+                        } else {
+                            if (perlane <= 1) FUSED_LAUNCH(false, 1); else if (perlane <= 4) FUSED_LAUNCH(false, 4);
+                            else if (perlane <= 16) FUSED_LAUNCH(false, 16); else FUSED_LAUNCH(false, 32);
+                        }
+#undef FUSED_LAUNCH
+                        HIPCHK(hipGetLastError());
+                    }
+                    if (dbg) {
+                        hipStreamSynchronize(st);
+                        t_rys = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+                        fprintf(stderr, "[mi355] eri class (%d%d|%d%d): %ld quartets, fused rys+transform+scatter %.4f s (%.2f ns/q)\n", B.la, B.lb,
                                 Kc.la, Kc.lb, (long)ntask, t_rys, t_rys / ntask * 1e9);
                     }
                     continue;

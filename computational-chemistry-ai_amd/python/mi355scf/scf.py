@@ -276,7 +276,11 @@ class SCF:
             # ~0.13 s of lazy initialisation (tools/wall_profile.py), a third of a cold benzene/cc-pVTZ kernel(); the warm-up
             # thread (engine._warm_libraries) has the device solver ready by the time the final eigh needs it.  Few BLAS
             # threads: an unlimited pool on a many-core host takes 50x longer on these sizes than four threads do.
-            from threadpoolctl import threadpool_limits
+            try:
+                from threadpoolctl import threadpool_limits
+            except ImportError:                 # no thread limiter: still correct, possibly slow on a many-core host
+                import contextlib
+                threadpool_limits = lambda limits: contextlib.nullcontext()
             with threadpool_limits(limits=4):
                 Lh = np.linalg.cholesky(S.cpu().numpy())    # raises numpy.linalg.LinAlgError for a linearly dependent basis
                 Li = np.linalg.inv(Lh)
@@ -739,6 +743,7 @@ class SCF:
         if self._nranks > 1:   # one-off: identical starting density on every rank (the atomic guess is built with atomics per rank)
             from . import parallel
             parallel.broadcast0(dm, self._pg)
+        self._fgraph = self._fgraph_seen = None     # a captured head belongs to one SCF (its CDIIS history buffers)
         st = {"nocc": mol.nelectron // 2, "enuc": mol.energy_nuc(), "cycle": 0, "diis": DeviceDIIS(eng, self.diis_space)}
         st["dmo"] = self._L.T @ dm @ self._L
         self._after_density(st, dm, e_last=None, next_cycle=0)
@@ -918,7 +923,7 @@ class SCF:
         m = min(diis.count, diis.space)
         key = (id(diis), m, self._sp2_plan_len, getattr(self, "_sp2_plan_gen", 0), self._Linv.data_ptr())
         g = self.__dict__.get("_fgraph")
-        if g is not None and g["key"] == key:
+        if g is not None and g["key"] == key and g["diis"] is diis:   # (the graph holds `diis` alive: its address cannot be reused)
             g["graph"].replay()
             self._sp2_hist_shape = None
             return dict(fo=g["fo"], dmo=g["dmo"], dm=g["dm"], tr=g["tr"], shape=g["shape"], planned=True)
@@ -946,7 +951,7 @@ class SCF:
             with torch.cuda.graph(graph):
                 fo, dmo, dm, tr_dev, shape = body()
             graph.replay()                   # the capture itself executes nothing
-            self._fgraph = dict(key=key, graph=graph, fo=fo, dmo=dmo, dm=dm, tr=tr_dev, shape=shape)
+            self._fgraph = dict(key=key, diis=diis, graph=graph, fo=fo, dmo=dmo, dm=dm, tr=tr_dev, shape=shape)
             return dict(fo=fo, dmo=dmo, dm=dm, tr=tr_dev, shape=shape, planned=True)
         except Exception as e:   # capture not possible on this stack: stay eager for good
             self.graph_front = False

@@ -56,6 +56,9 @@ def _worker(rank, world, port, q):
     ref = outs[-1].clone()
     parallel.broadcast0(ref)
     ok = ok and float((outs[-1] - ref).abs().max()) == 0.0
+    # set-up agreement used for the direct-mode split: element-wise MAX over ranks (pass -x for a minimum)
+    got = parallel.agree_max([float(rank), 10.0 - rank, -(100.0 + rank)])
+    ok = ok and got == [float(world - 1), 10.0, -100.0]
     q.put((rank, bool(ok)))
     import torch.distributed as dist
     dist.destroy_process_group()
