@@ -317,6 +317,7 @@ struct mi_ctx {
     int opt_tri_tiles = 1;   // block-diagonal tiles store triangular rows (0: the full-row layout of round 1); next mi_eri_prepare
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
+    int opt_jk_kjlt = 0;     // J+K: K_JL reduced per tile instead of run-wide accumulators (two waves per SIMD), experiment
     int opt_jk_dpp = 1;      // per-tile reduce-scatters of the J/K kernel through DPP moves (0: ds_bpermute, the round-1/2 path)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
     int opt_ao_order = 1;    // tile AO order: 1 = angular-momentum major (all s, all p, ... ; tiles become class-homogeneous), 0 = caller's
@@ -331,6 +332,8 @@ struct mi_ctx {
     // many small ones (drain + ramp of latency-bound waves per launch); keeping a batch inside the Infinity Cache buys nothing
     int opt_work_mb = 2048;
     int opt_grad_work_mb = 1024;
+    int opt_vmat_fold_mt = 3;   // xc_vmat_fold: 64-row tiles per workgroup (1..5)
+    int opt_rys_fine = 1;    // Rys kernel: also 2 and 8 components per lane (fewer registers, more waves for the classes in between)
     int opt_eri_fused = 0;   // mid / high classes: fused Rys + transform + scatter kernel (1) instead of the two-launch pair with its hand-over buffer -- measured SLOWER (0.273 vs 0.245 s): default off
     int opt_task_table = 1;  // wave-per-quartet kernels read (bra, ket) of a task from a table written once per class pair
     int opt_prim_lds = 0;    // Rys kernel: primitive-pair records of the quartet staged in LDS
@@ -565,6 +568,7 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_nt") c->opt_jk_nt = (int)value;
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else if (k == "jk_dpp") c->opt_jk_dpp = (int)value;
+    else if (k == "jk_kjlt") c->opt_jk_kjlt = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
     else if (k == "jk_pair") c->opt_jk_pair = (int)value;
     else if (k == "sp2_persist") c->opt_sp2_persist = (int)value;
@@ -577,6 +581,8 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "prim_lds") c->opt_prim_lds = (int)value;
     else if (k == "task_table") c->opt_task_table = (int)value;
     else if (k == "eri_fused") c->opt_eri_fused = (int)value;
+    else if (k == "rys_fine") c->opt_rys_fine = (int)value;
+    else if (k == "vmat_fold_mt") c->opt_vmat_fold_mt = (int)value;
     else if (k == "work_mb") c->opt_work_mb = (int)value;
     else if (k == "grad_work_mb") c->opt_grad_work_mb = (int)value;
     else if (k == "rys_qpw_maxcomp") c->opt_rys_qpw_maxcomp = (int)value;
@@ -1869,7 +1875,9 @@ static int launch_eri(mi_ctx *c, EriArgs &E, int nblocks, hipStream_t st)
     }
     size_t shm = sizeof(double) * ((size_t)E.PB * E.nroots * 3 * E.tsz + (size_t)E.PB * 2 * E.nroots + (size_t)E.prim_lds * 8);
     if (perlane <= 1) hipLaunchKernelGGL((eri_rys_kernel<1, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
+    else if (perlane <= 2 && c->opt_rys_fine) hipLaunchKernelGGL((eri_rys_kernel<2, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
     else if (perlane <= 4) hipLaunchKernelGGL((eri_rys_kernel<4, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
+    else if (perlane <= 8 && c->opt_rys_fine) hipLaunchKernelGGL((eri_rys_kernel<8, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
     else if (perlane <= 16) hipLaunchKernelGGL((eri_rys_kernel<16, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
     else hipLaunchKernelGGL((eri_rys_kernel<32, 64>), dim3(eri_grid(nblocks, E.xcd)), dim3(64), shm, st, E);
     HIPCHK(hipGetLastError());
@@ -1917,6 +1925,7 @@ static int launch_eri_tpq(int la, int lb, int lc, int ld, const TpqArgs &Q, hipS
         TPQ_CASE(2, 1, 1, 0); TPQ_CASE(2, 2, 0, 0); TPQ_CASE(3, 0, 0, 0); TPQ_CASE(3, 0, 1, 0); TPQ_CASE(3, 0, 2, 0);
         TPQ_CASE(3, 1, 0, 0); TPQ_CASE(3, 2, 0, 0);
         TPQ_CASE(2, 1, 2, 0); TPQ_CASE(2, 2, 1, 0); TPQ_CASE(3, 3, 0, 0);   // 96 / 93 / 74 accumulators: one wave per SIMD, still ahead
+        TPQ_CASE(3, 1, 1, 0); TPQ_CASE(3, 0, 1, 1); TPQ_CASE(3, 0, 3, 0);   // round 3 candidates: 75 / 90 / 100 accumulators
     default: return 0;
     }
 #undef TPQ_CASE
@@ -1924,7 +1933,8 @@ static int launch_eri_tpq(int la, int lb, int lc, int ld, const TpqArgs &Q, hipS
 static bool tpq_has_class(int la, int lb, int lc, int ld)
 {
     static const int keys[][4] = {{0,0,0,0},{1,0,0,0},{1,0,1,0},{1,1,0,0},{1,1,1,0},{2,0,0,0},{2,0,1,0},{2,0,1,1},{2,0,2,0},{2,1,0,0},
-                                  {2,1,1,0},{2,2,0,0},{3,0,0,0},{3,0,1,0},{3,0,2,0},{3,1,0,0},{3,2,0,0},{2,1,2,0},{2,2,1,0},{3,3,0,0}};
+                                  {2,1,1,0},{2,2,0,0},{3,0,0,0},{3,0,1,0},{3,0,2,0},{3,1,0,0},{3,2,0,0},{2,1,2,0},{2,2,1,0},{3,3,0,0},
+                                  {3,1,1,0},{3,0,1,1},{3,0,3,0}};
     for (const auto &k : keys) if (k[0] == la && k[1] == lb && k[2] == lc && k[3] == ld) return true;
     return false;
 }
@@ -2806,7 +2816,10 @@ __device__ __forceinline__ d2_t jk_load_chunk(const d2_t *__restrict__ tile, int
 // help (498 registers, 2.19 ms).  For the Coulomb-only build the same specialisation is harmless but its gain (0.742 vs 0.754-0.772
 // ms on one box, 0.770 vs 0.768-0.772 on another; +8 % on the cache-resident cc-pVDZ tensor) is within box-to-box noise: not kept.
 // Any rewrite has to bound the loads in flight by construction.
-template <bool WITH_J, bool WITH_K, bool NT, bool DIJ, bool DKL>
+// KJLT (round 3): K_JL is reduced over the 64 lanes PER TILE (8 DPP reduce-scatters over the k-lanes while the rows stream in,
+// one reduce-scatter over the i-lanes, one more 512-byte atomic) instead of living in 64 run-wide accumulators per lane: 128
+// registers less, which is what keeps the K-carrying kernel at one wave per SIMD.
+template <bool WITH_J, bool WITH_K, bool NT, bool DIJ, bool DKL, bool KJLT = false>
 __device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, const int i, const int k, const int I0, const int J0,
                                                const int K0, const int L0, const int ld, const int bk, const int64_t toff,
                                                const double (&dKL)[8], const double (&dJK)[8], double (&kjl)[8][8], double (&jkl)[8],
@@ -2823,9 +2836,9 @@ __device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, 
 #pragma unroll
     for (int l = 0; l < 8; l++) dIL[l] = D[(size_t)(I0 + i) * ld + L0 + l];
     const double dIK = D[(size_t)(I0 + i) * ld + K0 + k];
-    double kik = 0.0, jij[8], kil[8];
+    double kik = 0.0, jij[8], kil[8], kjl_row[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { jij[j] = 0.0; kil[j] = 0.0; }
+    for (int j = 0; j < 8; j++) { jij[j] = 0.0; kil[j] = 0.0; kjl_row[j] = 0.0; }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         double v[8];
@@ -2835,13 +2848,14 @@ __device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, 
             v[2 * lp] = x.x; v[2 * lp + 1] = x.y;
         }
         const MI_CONST_AS double *dJL = Du + (size_t)(J0 + j) * ld + L0; // wave-uniform row (SGPRs)
+        double pjl[8];
 #pragma unroll
         for (int l = 0; l < 8; l++) {
             const double x = v[l];
             if (WITH_K) {
                 kik = fma(x, dJL[l], kik);
                 kil[l] = fma(x, dJK[j], kil[l]);
-                kjl[j][l] = fma(x, dIK, kjl[j][l]);
+                if (KJLT) pjl[l] = x * dIK; else kjl[j][l] = fma(x, dIK, kjl[j][l]);
                 kjk[j] = fma(x, dIL[l], kjk[j]);
             }
             if (WITH_J) {
@@ -2849,6 +2863,11 @@ __device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, 
                 jkl[l] = fma(x, dIJ[j], jkl[l]);
             }
         }
+        if (WITH_K && KJLT) kjl_row[j] = reduce8_low(pjl, lane);   // sum over the 8 k-lanes of this i; lane holds l = k
+    }
+    if (WITH_K && KJLT) {
+        const double r = reduce8(kjl_row, lane, 32, 16, 8);          // sum over the 8 i-lanes; lane holds j = i
+        atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + L0 + k], r);
     }
     // per-tile outputs: three wave-wide FP64 atomics (1.5 KB added per 32 KB tile; executed at the memory side, not in L2).
     // Their cost, measured by dropping them (wrong J/K, timing only; benzene/cc-pVTZ, same box): J+K launch 0.752 ms without,
@@ -2865,7 +2884,7 @@ __device__ __forceinline__ void jk_digest_tile(const JkArgs &A, const int lane, 
     }
 }
 
-template <bool WITH_J, bool WITH_K, bool NT, bool PAIR = false>
+template <bool WITH_J, bool WITH_K, bool NT, bool PAIR = false, bool KJLT = false>
 __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
 {
     const int lane = threadIdx.x & 63;
@@ -2906,7 +2925,7 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
             const int64_t toff = off_next;
             if (R.count > 1) { I_next = tile_I[R.first + 1]; off_next = tile_off[R.first + 1]; }
             if (PAIR && A.pair_sync) __syncthreads();   // the two waves of a pair stay within one tile of each other: the second reader hits L2
-            jk_digest_tile<WITH_J, WITH_K, NT, true, true>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
+            jk_digest_tile<WITH_J, WITH_K, NT, true, true, KJLT>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
             t = 1;
         }
         for (; t < R.count; t++) {
@@ -2914,7 +2933,7 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
             const int64_t toff = off_next;
             if (t + 1 < R.count) { I_next = tile_I[R.first + t + 1]; off_next = tile_off[R.first + t + 1]; }
             if (PAIR && A.pair_sync) __syncthreads();   // the two waves of a pair stay within one tile of each other: the second reader hits L2
-            jk_digest_tile<WITH_J, WITH_K, NT, false, true>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
+            jk_digest_tile<WITH_J, WITH_K, NT, false, true, KJLT>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
         }
     } else {
         if (A.tri && I_next == R.J) {
@@ -2922,7 +2941,7 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
             const int64_t toff = off_next;
             if (R.count > 1) { I_next = tile_I[R.first + 1]; off_next = tile_off[R.first + 1]; }
             if (PAIR && A.pair_sync) __syncthreads();   // the two waves of a pair stay within one tile of each other: the second reader hits L2
-            jk_digest_tile<WITH_J, WITH_K, NT, true, false>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
+            jk_digest_tile<WITH_J, WITH_K, NT, true, false, KJLT>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
             t = 1;
         }
         for (; t < R.count; t++) {
@@ -2930,7 +2949,7 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
             const int64_t toff = off_next;
             if (t + 1 < R.count) { I_next = tile_I[R.first + t + 1]; off_next = tile_off[R.first + t + 1]; }
             if (PAIR && A.pair_sync) __syncthreads();   // the two waves of a pair stay within one tile of each other: the second reader hits L2
-            jk_digest_tile<WITH_J, WITH_K, NT, false, false>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
+            jk_digest_tile<WITH_J, WITH_K, NT, false, false, KJLT>(A, lane, i, k, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk);
         }
     }
     // per-run outputs
@@ -2942,6 +2961,7 @@ __device__ __forceinline__ void jk_segment(const JkArgs &A, const int seg)
         double r = reduce8(kjk, lane, 32, 16, 8); // lane holds j = i
         atomicAdd(&A.Kacc[(size_t)(J0 + i) * ld + K0 + k], r);
         // K_JL: 64 values over 64 lanes; first over i-lanes for each l-row... do it as 8 x reduce8 then reduce8
+        if (KJLT) return;   // (already added per tile)
         double s[8];
 #pragma unroll
         for (int l = 0; l < 8; l++) {
@@ -2977,6 +2997,17 @@ __global__ __launch_bounds__(64) void jk_tiles_kernel(JkArgs A)
 // single-density kernel, on two SIMDs of one CU.  Both read the same tiles; a barrier per tile keeps them within one tile of
 // each other, so the second reader of a 16-byte chunk finds it in L2 (default cache policy: no nontemporal hint here) and
 // HBM is read once for both densities.
+// J+K with K_JL reduced per tile (KJLT): 128 registers fewer, so two waves fit a SIMD (jk_kjlt option)
+template <bool NT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void jk_tiles_kjlt_kernel(JkArgs A)
+{
+    const MI_CONST_AS int *wave_seg = as_const(A.wave_seg);
+    const int seg_end = wave_seg[blockIdx.x + 1];
+    for (int seg = wave_seg[blockIdx.x]; seg < seg_end; seg++) {
+        if (NT && seg < A.n_cached) jk_segment<true, true, false, false, true>(A, seg);
+        else jk_segment<true, true, NT, false, true>(A, seg);
+    }
+}
 template <bool WITH_J, bool WITH_K, bool NT>
 __global__ __launch_bounds__(128) void jk_tiles_pair_kernel(JkArgs A)
 {
@@ -3272,6 +3303,7 @@ static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
         if (wj) { if (nt) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, true, false>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, false, false>), g, b, 0, st, A); }
         else hipLaunchKernelGGL((jk_tiles_pipe_kernel<false, true, false>), g, b, 0, st, A);
     }
+    else if (wj && wk && c->opt_jk_kjlt) { if (nt) hipLaunchKernelGGL((jk_tiles_kjlt_kernel<true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kjlt_kernel<false>), g, b, 0, st, A); }
     else if (wj && wk) { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<true, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<true, true, false>), g, b, 0, st, A); }
     else if (wj) { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<true, false, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<true, false, false>), g, b, 0, st, A); }
     else { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<false, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<false, true, false>), g, b, 0, st, A); }
@@ -6478,4 +6510,154 @@ extern "C" int mi_xc_vmat(mi_ctx *c, const double *d_ao0, const double *d_aow, i
                        d_vmat, xcd_order);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// =================================================================================================
+// Vxc accumulation with the weighted AOs formed ON THE FLY (round 3):  C[m][n] += sum_g ao_0[m][g] * W[n][g],
+//   W[n][g] = sum_c wv_c[g] ao_c[n][g]   (c = 0 for LDA, 0..3 for GGA)  -- what xc_aow_kernel used to write out and xc_vmat_kernel
+// to read back (a 1.3 GB pass of 0.24 ms per build on benzene/cc-pVTZ that existed only to feed this product).
+// Tiling: a workgroup owns MT x 64 rows (up to ALL rows of the matrix) x 64 columns and a slice of the grid points, so the
+// four AO components of the B operand are read ONCE per row block instead of once per 64-row tile, and a wave holds MT x 4
+// MFMA tiles (16 MT rows x 64 columns): MT + 4 LDS operand reads feed 4 MT v_mfma_f64_16x16x4_f64 per k step (0.45 reads per
+// MFMA at MT = 5 against 1.0 in xc_vmat_kernel, whose counters show 52 % issue stalls at 42 % of the MFMA peak).
+// =================================================================================================
+#define VF_KS 16
+#define VF_PAD 2
+#define VF_THREADS 256
+// 256 threads = 4 waves, wave w owns the 16 MT rows of slab w and all 64 columns (MT x 4 MFMA tiles), 16-point chunks.
+// MEASURED SLOWER than the xc_aow + xc_vmat pair it was meant to replace (benzene/cc-pVTZ, 123 k points; the pair: 0.24 + 0.51 ms):
+//   this kernel, MT = 1 / 2 / 3 (two waves per SIMD)                         1.78 / 1.26 / 1.15 ms
+//   MT = 5 (all 264 rows in one workgroup, 336 VGPRs, one wave per SIMD)        1.45 ms with 32-point chunks; forced to 256 VGPRs: 2.2 ms
+//   MT = 5, 512 threads, double-buffered LDS stage, one workgroup per CU      0.88 ms (32.5 % of the MFMA peak by the MOPS counter)
+// The four-component B operand costs 4 loads + 3 FMAs per element in the loader of a kernel whose limit is already the
+// load -> LDS -> MFMA hand-over (xc_vmat_kernel: 52 % issue stalls), and the row blocks that would amortise it do not fit the
+// registers of two waves per SIMD.  Kept as an option (`RKS.xc_vmat_fold`, default off), not used.
+template <int MT>
+__global__ __launch_bounds__(VF_THREADS) void xc_vmat_fold_kernel(const double *__restrict__ ao, const double *__restrict__ wv, int ncomp, int nao,
+                                                                  int64_t ng, int64_t kchunk, int nct, int nrb, double *C, int xcd_order)
+{
+    extern __shared__ double lds_all[];
+    constexpr int MR = MT * 64, LDS_LD = VF_KS + VF_PAD;
+    double *Pa = lds_all, *Pb = lds_all + (size_t)MR * LDS_LD;
+    const int ntt = nct * nrb;
+    const int L = (int)blockIdx.x;
+    int tile, split;
+    if (xcd_order) { split = (L & 7) + 8 * (L / (8 * ntt)); tile = (L >> 3) % ntt; }
+    else { tile = L % ntt; split = L / ntt; }
+    const int rb = tile / nct, ct = tile - rb * nct;
+    const int m0 = rb * MR, n0 = ct * 64;
+    const int64_t kbeg = (int64_t)split * kchunk, kend = min(ng, kbeg + kchunk);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wr0 = wave * (MT * 16);
+    const size_t comp = (size_t)nao * ng;
+    d4_t acc[MT][4];
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
+    constexpr int PA = MR * VF_KS / VF_THREADS, PB = 64 * VF_KS / VF_THREADS;   // 4 MT and 4 elements per thread
+    const int kq = threadIdx.x & (VF_KS - 1), rq = threadIdx.x >> 4;           // element u of a thread: row rq + 16 u, point kq
+    double ra[PA], rb_[PB];
+    auto gload = [&](int64_t k0) {
+        const int64_t g = k0 + kq;
+        const bool gv = g < kend;
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+        if (gv) {
+            w0 = wv[g];
+            if (ncomp > 1) { w1 = wv[ng + g]; w2 = wv[2 * ng + g]; w3 = wv[3 * ng + g]; }
+        }
+        const double *pa = ao + (size_t)(m0 + rq) * ng + g;
+#pragma unroll
+        for (int u = 0; u < PA; u++) ra[u] = (gv && m0 + rq + 16 * u < nao) ? pa[(size_t)(16 * u) * ng] : 0.0;
+        const double *pb = ao + (size_t)(n0 + rq) * ng + g;
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            double v = 0.0;
+            if (gv && n0 + rq + 16 * u < nao) {
+                const double *q = pb + (size_t)(16 * u) * ng;
+                v = q[0] * w0;
+                if (ncomp > 1) v = fma(q[comp], w1, fma(q[2 * comp], w2, fma(q[3 * comp], w3, v)));
+            }
+            rb_[u] = v;
+        }
+    };
+    if (kbeg < kend) gload(kbeg);
+    const bool rows_in = m0 + wr0 < nao;   // wave-uniform
+    for (int64_t k0 = kbeg; k0 < kend; k0 += VF_KS) {
+#pragma unroll
+        for (int u = 0; u < PA; u++) Pa[(rq + 16 * u) * LDS_LD + kq] = ra[u];
+#pragma unroll
+        for (int u = 0; u < PB; u++) Pb[(rq + 16 * u) * LDS_LD + kq] = rb_[u];
+        __syncthreads();
+        if (k0 + VF_KS < kend) gload(k0 + VF_KS);       // in flight while this chunk is multiplied
+        if (rows_in) {
+#pragma unroll
+            for (int kk = 0; kk < VF_KS; kk += 4) {
+                const int kc = kk + (lane >> 4);
+                double b[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[j] = Pb[(j * 16 + (lane & 15)) * LDS_LD + kc];
+#pragma unroll
+                for (int a = 0; a < MT; a++) {
+                    const double av = Pa[(wr0 + a * 16 + (lane & 15)) * LDS_LD + kc];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[a][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[j], acc[a][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = m0 + wr0 + a * 16 + (lane >> 4) + 4 * r, col = n0 + j * 16 + (lane & 15);   // f64 MFMA C/D layout
+                if (row < nao && col < nao) atomicAdd(&C[(size_t)row * nao + col], acc[a][j][r]);
+            }
+}
+
+template <int MT>
+static int launch_vmat_fold(mi_ctx *c, const double *d_ao, const double *d_wv, int ncomp, int64_t ng, int nrb, double *d_vmat, hipStream_t st)
+{
+    const int nct = (c->nao + 63) / 64, ntt = nct * nrb;
+    const size_t shm = sizeof(double) * (size_t)(MT * 64 + 64) * (VF_KS + VF_PAD);
+    // one workgroup per CU fits (LDS) at MT = 5: aim at one full round of workgroups, at least 512 points per split
+    const int64_t wgs = c->opt_vmat_wgs > 0 ? c->opt_vmat_wgs : 512;   // two workgroups per CU
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>((ng + 511) / 512, wgs / ntt));
+    int64_t kchunk = ((ng + nsplit - 1) / nsplit + VF_KS - 1) / VF_KS * VF_KS;
+    nsplit = (ng + kchunk - 1) / kchunk;
+    int xcd_order = 0;
+    const int64_t ns8 = nsplit / 8 * 8;
+    if (c->opt_vmat_xcd && ns8 >= 8 && ns8 * 10 >= nsplit * 9) {
+        nsplit = ns8;
+        kchunk = ((ng + nsplit - 1) / nsplit + VF_KS - 1) / VF_KS * VF_KS;
+        xcd_order = 1;
+    }
+    if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)xc_vmat_fold_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((xc_vmat_fold_kernel<MT>), dim3((unsigned)(ntt * nsplit)), dim3(VF_THREADS), shm, st, d_ao, d_wv, ncomp, c->nao, ng, kchunk, nct, nrb,
+                       d_vmat, xcd_order);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// d_ao: [ncomp >= 1 | 4][nao][ng] AO values (component 0 = values, 1..3 = gradient), d_wv: [1 | 4][ng] weights x potential
+// (as mi_xc_aow takes them), gga = 0: LDA (component 0 only).  d_vmat += ao_0 . (sum_c wv_c ao_c)^T, unsymmetrised.
+extern "C" int mi_xc_vmat_fold(mi_ctx *c, const double *d_ao, const double *d_wv, int64_t ng, int gga, double *d_vmat, void *stream)
+{
+    if (!c || !d_ao || !d_wv || !d_vmat) return fail("mi_xc_vmat_fold: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nt = (c->nao + 63) / 64;                 // 64-row tiles of the matrix
+    const int cap = std::max(1, std::min(5, c->opt_vmat_fold_mt));
+    const int nrb = (nt + cap - 1) / cap;              // row blocks of at most `cap` 64-row tiles (registers: two waves per SIMD up to 3)
+    const int mt = (nt + nrb - 1) / nrb;               // tiles per row block
+    const int ncomp = gga ? 4 : 1;
+    switch (mt) {
+    case 1: return launch_vmat_fold<1>(c, d_ao, d_wv, ncomp, ng, nrb, d_vmat, st);
+    case 2: return launch_vmat_fold<2>(c, d_ao, d_wv, ncomp, ng, nrb, d_vmat, st);
+    case 3: return launch_vmat_fold<3>(c, d_ao, d_wv, ncomp, ng, nrb, d_vmat, st);
+    case 4: return launch_vmat_fold<4>(c, d_ao, d_wv, ncomp, ng, nrb, d_vmat, st);
+    default: return launch_vmat_fold<5>(c, d_ao, d_wv, ncomp, ng, nrb, d_vmat, st);
+    }
 }

@@ -6,6 +6,8 @@ HYB_GGA_XC_B3LYP (VWN-RPA) as PySCF >= 2.3 does [MEM].  XC quadrature: HIP kerne
 density, functional (forward-mode dual numbers) and weighted AOs; the two dense contractions per grid
 block are rocBLAS DGEMMs (FP64 MFMA) through torch.matmul.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -138,8 +140,14 @@ class RKS(RHF):
             else:
                 e, wv = eng.xc_eval(terms, rho, w, gga)
             eng.xc_tail(w, (rho[0], e), tail)     # tail[0] += w.rho (N_elec), tail[1] += w.e (E_xc): one deterministic launch
-            aow = eng.xc_aow(ao, wv, gga)
-            eng.xc_vmat(ao[0], aow, vmat)      # vmat += ao0 . aow^T  (split-K FP64 MFMA kernel)
+            if os.environ.get("MI355_VMAT_MT") and not getattr(self, "_vmat_mt_set", False):
+                eng.set_option("vmat_fold_mt", float(os.environ["MI355_VMAT_MT"]))
+                self._vmat_mt_set = True
+            if self.xc_vmat_fold or os.environ.get("MI355_XC_FOLD", "0") == "1":
+                eng.xc_vmat_fold(ao, wv, gga, vmat)    # vmat += ao0 . (sum_c wv_c ao_c)^T, weighted AOs formed inside the MFMA kernel
+            else:
+                aow = eng.xc_aow(ao, wv, gga)
+                eng.xc_vmat(ao[0], aow, vmat)      # vmat += ao0 . aow^T  (split-K FP64 MFMA kernel)
             if gga == 2:                        # kinetic-energy-density term: sum_k ao_k . (w/4 vtau ao_k)^T
                 for k in (1, 2, 3):
                     eng.xc_vmat(ao[k], wv[4] * ao[k], vmat)
@@ -155,6 +163,7 @@ class RKS(RHF):
         import os
         return float(os.environ.get("MI355_XC_BLOCK_GB", self.xc_block_gb)) * 1e9
 
+    xc_vmat_fold = False  # V_xc product with the weighted AOs formed on the fly (round 3 experiment: 0.88-1.8 ms against 0.75 ms for the xc_aow pass + xc_vmat)
     xc_lowrank = True   # inside the SCF loop: rho from occupied-orbital values (D = Z Z^T) instead of D.ao
     xc_lowrank_min_nao = 128   # below this the dozen small launches of the factorisation cost more than the D.ao GEMM (CH3/cc-pVTZ UKS: 2.9 -> 3.4 ms)
 

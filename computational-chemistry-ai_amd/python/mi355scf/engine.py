@@ -90,6 +90,7 @@ def lib():
         L.mi_xc_eval_mgga.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, i64, vp, vp, vp]
         L.mi_xc_eval_mgga_spin.argtypes = [ip, dp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.mi_xc_vmat.argtypes = [vp, vp, vp, i64, vp, vp]
+        L.mi_xc_vmat_fold.argtypes = [vp, vp, vp, i64, ctypes.c_int, vp, vp]
         L.mi_nystrom_warm.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]
         L.mi_xc_tail.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
         L.mi_build_fock.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_double, vp, vp, vp]
@@ -443,6 +444,10 @@ class Engine:
         aow = self._new(self.nao, ng)
         _check(lib().mi_xc_aow(self._h, ao.data_ptr(), wv.data_ptr(), ng, int(gga), aow.data_ptr(), self._stream()))
         return aow
+
+    def xc_vmat_fold(self, ao, wv, gga, vmat):
+        """vmat += ao_0 . (sum_c wv_c ao_c)^T with the weighted AOs formed inside the kernel (no `xc_aow` pass)."""
+        _check(lib().mi_xc_vmat_fold(self._h, ao.data_ptr(), wv.data_ptr(), ao.shape[-1], int(bool(gga)), vmat.data_ptr(), self._stream()))
 
     def xc_vmat(self, ao0, aow, vmat):
         _check(lib().mi_xc_vmat(self._h, ao0.data_ptr(), aow.data_ptr(), ao0.shape[-1], vmat.data_ptr(), self._stream()))

@@ -305,6 +305,10 @@ int mi_xc_eval_mgga_spin(const int32_t *kinds, const double *coefs, int nterms, 
 /* d_vmat[nao][nao] += ao0 . aow^T over the grid block (split-K FP64 MFMA kernel; rocBLAS has no split-K for
  * this tiny-M,N / huge-K shape and runs it at < 1 TFLOP/s).  The caller symmetrises (Vxc = vmat + vmat^T). */
 int mi_xc_vmat(mi_ctx *ctx, const double *d_ao0, const double *d_aow, int64_t ng, double *d_vmat, void *stream);
+/* Round 3: the same accumulation with the weighted AOs formed on the fly from the AO values and the weights x potential that
+ * mi_xc_aow would take (d_ao [1|4][nao][ng], d_wv [1|4][ng], gga = 0: LDA): d_vmat += ao_0 . (sum_c wv_c ao_c)^T.  Replaces the
+ * mi_xc_aow + mi_xc_vmat pair of numint.nr_rks's `_scale_ao` + `ao.T @ aow` [MEM] for LDA / GGA functionals. */
+int mi_xc_vmat_fold(mi_ctx *ctx, const double *d_ao, const double *d_wv, int64_t ng, int gga, double *d_vmat, void *stream);
 
 /* Real-solid-harmonic coefficient table used by the kernels: out[ncart(l)][2l+1] (host). */
 int mi_c2s_table(int l, double *out);

@@ -129,3 +129,23 @@ def test_rks_energy_vs_committed_oracle_golden(key, mol_name, xc):
     assert mf.converged and abs(mf.grids.size - g["ngrids"]) < 0.06 * g["ngrids"]
     assert abs(e - g["e_tot"]) < 2e-7, (e, g["e_tot"])
     assert abs(float(mf._nelec_grid) - g["nelec_grid"]) < 1e-7
+
+
+def test_vxc_product_with_weighted_aos_formed_in_kernel_matches_two_pass_path():
+    """`mi_xc_vmat_fold` (round-3 experiment, default off: DESIGN.md 8.8) forms sum_c wv_c ao_c inside the MFMA kernel; it must give
+    the V_xc matrix of the xc_aow + xc_vmat pair (LDA and GGA, N not a multiple of 64, several row blocks)."""
+    from pyscf import gto, dft
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.verbose = "C 0 0 0; O 1.2 0 0; H -0.5 0.9 0; H -0.5 -0.9 0", "cc-pVDZ", 0
+    mol.build()
+    for xc in ("LDA,VWN", "PBE", "B3LYP"):
+        ref = dft.RKS(mol); ref.xc = xc
+        ref.kernel()
+        dm = ref.make_rdm1()
+        v0 = ref.get_veff(dm=dm)
+        ref.xc_vmat_fold = True          # same object: same (pruned) grid, same AO cache
+        for mt in (1, 3, 5):
+            ref.engine.set_option("vmat_fold_mt", mt)
+            v1 = ref.get_veff(dm=dm)
+            assert np.abs(v1 - v0).max() < 1e-10, (xc, mt, np.abs(v1 - v0).max())
+        assert np.abs(v0).max() > 0.1

@@ -38,6 +38,28 @@ def test_szabo_ostlund_h2_sto3g():
     assert abs(r["e_tot"] - (-1.1167)) < 1e-4
 
 
+def test_szabo_ostlund_heh_cation_sto3g():
+    """Szabo & Ostlund, Modern Quantum Chemistry, section 3.5.3 / appendix B: HeH+ at R = 1.4632 a0, STO-3G with zeta(He) = 2.0925,
+    zeta(H) = 1.24 (exponents scale with zeta^2).  Book values [MEM, 4 decimals]: S12 = 0.4508, T11 = 2.1643, T12 = 0.1670, T22 =
+    0.7600, (11|11) = 1.3072, (21|11) = 0.4373, (21|21) = 0.1773, (22|11) = 0.6057, (22|21) = 0.3118, (22|22) = 0.7746, electronic
+    energy -4.227529, total energy -2.860662 (the book's own SCF used the 4-decimal integrals: agreement to 1e-5)."""
+    from oracle import oracle as orc
+    base = [(2.227660584, 0.154328967), (0.405771156, 0.535328142), (0.109818, 0.444634542)]
+    sto = lambda z: [[0] + [[a * z * z, c] for a, c in base]]
+    mol = _mol("He 0 0 0; H 0 0 1.4632", {"He": sto(2.0925), "H": sto(1.24)}, unit="Bohr", charge=1)
+    o = orc.Oracle(mol)
+    S, T, V, _ = o.int1e()
+    eri = o.eri_full()
+    assert abs(S[0, 1] - 0.4508) < 1e-4
+    assert abs(T[0, 0] - 2.1643) < 1e-4 and abs(T[0, 1] - 0.1670) < 1e-4 and abs(T[1, 1] - 0.7600) < 1e-4
+    for (i, j, k, l), ref in (((0, 0, 0, 0), 1.3072), ((1, 0, 0, 0), 0.4373), ((1, 0, 1, 0), 0.1773), ((1, 1, 0, 0), 0.6057),
+                              ((1, 1, 1, 0), 0.3118), ((1, 1, 1, 1), 0.7746)):
+        assert abs(eri[i, j, k, l] - ref) < 1e-4, (i, j, k, l, eri[i, j, k, l])
+    assert abs(mol.energy_nuc() - 1.366867) < 1e-6
+    r = orc.rhf(mol)
+    assert abs(r["e_tot"] - (-2.860662)) < 1e-5
+
+
 def test_crawford_h2o_sto3g():
     from oracle import oracle as orc
     mol = _mol("O 0 -0.143225816552 0; H 1.638036840407 1.136548822547 0; H -1.638036840407 1.136548822547 0",
