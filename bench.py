@@ -31,6 +31,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.
 PMC_FILE = os.path.join("profiles", "r02_pmc_jk_traffic.json")
 
 
+def cpu_share():
+    """CPUs this process may really use: min(affinity mask, cgroup v2 quota), at least 1."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(mol, label, budget_s=40.0):
     """CPU oracle, kind "port", IN-CORE: what PySCF's CPU rung (`templates/calculate_energy.py:199-206`) does at this size --
     the 8-fold-unique ERIs are evaluated once into host memory (4.9 GB at N = 264) and every cycle digests that array
@@ -39,6 +51,10 @@ def cpu_baseline(mol, label, budget_s=40.0):
     The same pack time, scaled, is what ONE cycle of a direct (recompute) CPU SCF costs (`direct_*` keys)."""
     import numpy as np
     from oracle import oracle as orc
+    # threads = the CPU share this process really has: a GPU box of the pool shows 256 logical CPUs but grants 16 (cgroup
+    # cpu.max); 128 OpenMP threads on that quota ran the in-core digestion 4x SLOWER than 32 (0.20 s against 0.046 s)
+    share = cpu_share()
+    orc.Oracle.set_num_threads(share)
     n = mol.nao
     npair = n * (n + 1) // 2
     total = npair * (npair + 1) // 2
@@ -77,17 +93,26 @@ def cpu_baseline(mol, label, budget_s=40.0):
     else:
         t_jk_full = t_jk
     diis = orc.CDIIS()
-    t0 = time.time()
-    for _ in range(reps):                             # the rest of a cycle at full size (independent of the sample)
-        f = diis.update(S, dm, h + J - 0.5 * K)
-        e, c = orc.eig_gen(f, S)
-        dm2 = 2.0 * c[:, :nocc] @ c[:, :nocc].T
-        _ = float(np.sum(dm2 * (h + f)))
-    t_rest = (time.time() - t0) / reps
+    try:                                              # N = 264 LAPACK / BLAS calls: a 128-thread pool is 10x SLOWER than 8 threads
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        import contextlib
+        threadpool_limits = lambda limits: contextlib.nullcontext()
+    with threadpool_limits(limits=min(8, share)):
+        f = diis.update(S, dm, h + J - 0.5 * K)       # (untimed first pass: thread-pool start-up)
+        orc.eig_gen(f, S)
+        diis = orc.CDIIS()
+        t0 = time.time()
+        for _ in range(reps):                         # the rest of a cycle at full size (independent of the sample)
+            f = diis.update(S, dm, h + J - 0.5 * K)
+            e, c = orc.eig_gen(f, S)
+            dm2 = 2.0 * c[:, :nocc] @ c[:, :nocc].T
+            _ = float(np.sum(dm2 * (h + f)))
+        t_rest = (time.time() - t0) / reps
     t_cycle = t_jk_full + t_rest
     t_direct = t_pack / frac + t_rest
     what = "all rows" if stride == 1 else f"rows of every {stride}th shell pair ({100 * frac:.1f} % of the array, J/K time scaled by 1/fraction)"
-    return {"value": 1.0 / t_cycle, "unit": "iter/s", "cores": orc.Oracle.num_threads(), "kind": "port", "mode": "in-core",
+    return {"value": 1.0 / t_cycle, "unit": "iter/s", "cores": orc.Oracle.num_threads(), "cpus_visible": os.cpu_count(), "kind": "port", "mode": "in-core",
             "sample": f"in-core SCF cycle of {label} (N={n}) with the in-repo CPU oracle (not PySCF): packed 8-fold ERI array "
                       f"{total * 8e-9:.2f} GB, {what}; J/K digestion {t_jk_full:.3f} s + CDIIS/eig/density {t_rest:.3f} s per cycle; "
                       f"one-off ERI evaluation {t_pack / frac:.1f} s (excluded, like eri_seconds on the GPU); CPU work in this leg {t_probe + t_pack + (reps + 1) * t_jk:.0f} s",

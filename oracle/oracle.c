@@ -767,46 +767,87 @@ void orc_jk_incore(const int *bas, int nbas, const long *row_off, const double *
     for (int I = nao - 1; I >= 0; I--)
         for (int Jx = I; Jx >= 0; Jx--)
             if (row_off[(long)I * (I + 1) / 2 + Jx] >= 0) { rowI[nrows] = I; rowJ[nrows] = Jx; nrows++; }
-#pragma omp parallel
+    /* thread-private accumulators in one block, summed afterwards by ALL threads (each a slice of the matrix): a critical
+     * section here serialised 128 x 2 N^2 additions -- a third of the digestion time of benzene/cc-pVTZ on 128 threads.
+     * The inner loop is branch-free: every element is digested with the row weight, the two special elements of a row
+     * segment -- (K,K), weight 1/2, and the last element (ij|ij), another 1/2 -- are corrected afterwards. */
+    int nth = 1;
+#ifdef _OPENMP
+    nth = omp_get_max_threads();
+#endif
+    double *acc = (double *)malloc((size_t)nth * 2 * nn * sizeof(double));
+#pragma omp parallel num_threads(nth)
     {
-        double *Ja = (double *)calloc(nn, sizeof(double)), *Ka = (double *)calloc(nn, sizeof(double));
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        double *Ja = acc + (size_t)tid * 2 * nn, *Ka = Ja + nn;
+        memset(Ja, 0, 2 * nn * sizeof(double));     /* first touch by the owner */
 #pragma omp for schedule(dynamic, 16)
         for (long r = 0; r < nrows; r++) {
-            {
-                const int I = rowI[r], Jx = rowJ[r];
-                long ij = (long)I * (I + 1) / 2 + Jx;
-                const double *row = buf + row_off[ij];
-                const double wij = (I == Jx) ? 0.5 : 1.0;
-                const double dij = D[(size_t)I * nao + Jx];
-                double jij = 0.0;
-                long kl = 0;
-                for (int Kx = 0; Kx <= I; Kx++) {
-                    const int lmax = (Kx == I) ? Jx : Kx;
-                    const double dik = D[(size_t)I * nao + Kx], djk = D[(size_t)Jx * nao + Kx];
-                    double kik = 0.0, kjk = 0.0;
-                    for (int Lx = 0; Lx <= lmax; Lx++, kl++) {
-                        double v = row[kl] * wij;
-                        if (Kx == Lx) v *= 0.5;
-                        if (kl == ij) v *= 0.5;
-                        jij += v * D[(size_t)Kx * nao + Lx];
-                        Ja[(size_t)Kx * nao + Lx] += v * dij;
-                        kik += v * D[(size_t)Jx * nao + Lx];
-                        Ka[(size_t)I * nao + Lx] += v * djk;
-                        kjk += v * D[(size_t)I * nao + Lx];
-                        Ka[(size_t)Jx * nao + Lx] += v * dik;
-                    }
-                    Ka[(size_t)I * nao + Kx] += kik;
-                    Ka[(size_t)Jx * nao + Kx] += kjk;
+            const int I = rowI[r], Jx = rowJ[r];
+            const long ij = (long)I * (I + 1) / 2 + Jx;
+            const double *row = buf + row_off[ij];
+            const double W = (I == Jx) ? 0.5 : 1.0;
+            const double *DI = D + (size_t)I * nao, *DJ = D + (size_t)Jx * nao;
+            double *KI = Ka + (size_t)I * nao, *KJ = Ka + (size_t)Jx * nao;
+            const double dijW = DI[Jx] * W;
+            double jij = 0.0;
+            long kl = 0;
+            for (int Kx = 0; Kx <= I; Kx++) {
+                const int lmax = (Kx == I) ? Jx : Kx;
+                const double *seg = row + kl, *DK = D + (size_t)Kx * nao;
+                double *JK = Ja + (size_t)Kx * nao;
+                const double dikW = DI[Kx] * W, djkW = DJ[Kx] * W;
+                double kik = 0.0, kjk = 0.0, js = 0.0;
+                for (int Lx = 0; Lx <= lmax; Lx++) {
+                    const double v = seg[Lx];
+                    js += v * DK[Lx];
+                    JK[Lx] += v * dijW;
+                    kik += v * DJ[Lx];
+                    KI[Lx] += v * djkW;
+                    kjk += v * DI[Lx];
+                    KJ[Lx] += v * dikW;
                 }
-                Ja[(size_t)I * nao + Jx] += jij;
+                if (lmax == Kx) {            /* (K,K) carries weight 1/2: take half of it back */
+                    const double c = -0.5 * seg[Kx];
+                    js += c * DK[Kx];
+                    JK[Kx] += c * dijW;
+                    kik += c * DJ[Kx];
+                    KI[Kx] += c * djkW;
+                    kjk += c * DI[Kx];
+                    KJ[Kx] += c * dikW;
+                }
+                if (Kx == I) {               /* last element of the row, (ij|ij): another factor 1/2 */
+                    const double c = -0.5 * ((I == Jx) ? 0.5 : 1.0) * seg[Jx];
+                    js += c * DK[Jx];
+                    JK[Jx] += c * dijW;
+                    kik += c * DJ[Jx];
+                    KI[Jx] += c * djkW;
+                    kjk += c * DI[Jx];
+                    KJ[Jx] += c * dikW;
+                }
+                KI[Kx] += kik * W;
+                KJ[Kx] += kjk * W;
+                jij += js;
+                kl += lmax + 1;
+            }
+            Ja[(size_t)I * nao + Jx] += jij * W;
+        }
+        /* every thread sums one contiguous slice of [J|K] over the thread copies (contiguous reads per copy) */
+        {
+            const long tot = 2 * (long)nn, per = (tot + nth - 1) / nth;
+            const long lo = (long)tid * per, hi = (lo + per < tot) ? lo + per : tot;
+            for (long n = lo; n < hi; n++) { if (n < (long)nn) J[n] = 0.0; else K[n - nn] = 0.0; }
+#pragma omp barrier
+            for (int t = 0; t < nth; t++) {
+                const double *src = acc + (size_t)t * 2 * nn;
+                for (long n = lo; n < hi; n++) { if (n < (long)nn) J[n] += src[n]; else K[n - nn] += src[n]; }
             }
         }
-#pragma omp critical
-        {
-            for (size_t n = 0; n < nn; n++) { J[n] += Ja[n]; K[n] += Ka[n]; }
-        }
-        free(Ja); free(Ka);
     }
+    free(acc);
     free(rowI); free(rowJ);
     for (int a = 0; a < nao; a++)
         for (int b = 0; b <= a; b++) {
@@ -872,6 +913,16 @@ void orc_jk_shellblock(const int *atm, int natm, const int *bas, int nbas, const
     }
     free_pair(&ab);
     free(loc);
+}
+
+/* number of OpenMP threads the following calls use (bench.py: the CPU share the container really has, cgroup cpu.max) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 int orc_num_threads(void)

@@ -124,6 +124,10 @@ class Oracle:
     def num_threads():
         return lib().orc_num_threads()
 
+    @staticmethod
+    def set_num_threads(n):
+        lib().orc_set_num_threads(int(n))
+
 
 # ------------------------------------------------------------------------------------------------
 
