@@ -294,6 +294,7 @@ class _GradScanner:
         # benzene 20 instead of 14 (tools/opt_variants.py): Gram-Schmidt in AO order drags every later atom's functions along
         dm0 = mf.make_rdm1() if mf.mo_coeff is not None else None
         mf.reset(mol)
+        mf._grad_prefetch = True      # the gradient's host-side set-up overlaps this SCF (engine option `grad_prefetch`)
         e = mf.kernel(dm0=dm0)
         self.converged = mf.converged
         self.g.mol = self.mol = mol

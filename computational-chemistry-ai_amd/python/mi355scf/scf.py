@@ -301,6 +301,10 @@ class SCF:
                              f"{8e-9 * self.with_df.naux * eng.nao ** 2:.2f} GB, built in {self.timing['df_seconds']:.3f} s")
         elif not eng.eri_ready and self._stream_groups <= 1:
             oom = False
+            if getattr(self, "_grad_prefetch", False):
+                # a gradient follows this SCF (geometry optimisation, scanner): the host half of its set-up runs on a helper
+                # thread of the library while the SCF loop keeps the device busy
+                eng.set_option("grad_prefetch", 1)
             try:
                 st = eng.prepare_eri(self.direct_scf_tol, self._rank, self._nranks)
                 self.timing["eri_seconds"] = st["seconds_eri"]
