@@ -5151,12 +5151,19 @@ struct GradXfArgs {
     const double *q_bra, *q_ket, *dmax; // same screening as EriArgs (the Rys kernel left these quartets' blocks unwritten)
     int nbas_d;
     double dtol;
+    // density fitting (mi_df_grad, template flag DF): the two-particle density is not a product of D's but a dense tensor,
+    // G[(a b), (P)] = Z[a * zs_i + b * zs_j + P]  (three-index: Z3[a][b][P]; two-index: Z2[P][Q], zs_j = 0), the ket is an
+    // auxiliary "pair" (P, unit function) whose atoms come from `ket_atom`, and the weight is w0 instead of 4.
+    const double *Z;
+    int64_t zs_i, zs_j;
+    const int *ket_atom;
+    double w0;
 };
 #define GRAD_COPIES 4096
 
 // GSZ = lanes per quartet: 16 (four quartets per wave, small angular classes) or 64 (256 = four waves sharing one
 // quartet's LDS blocks is supported by the code but was measured slower and is not launched).
-template <int GSZ, bool MFMA>
+template <int GSZ, bool MFMA, bool DF = false>
 __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfArgs A)
 {
     // sum_{x-independent part first}:  g[x] = sum_{r,e} M^x[r][e] * Z[r][e],  Z[r][e] = sum_f E0[e][f] Y[r][f],
@@ -5199,6 +5206,7 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
             int r = o / A.nscd, c = o - r * A.nscd;
             int sa = r / A.ns2, sb = r - sa * A.ns2, sc = c / A.nsd, sd = c - sc * A.nsd;
             int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
+            if (DF) { G[o] = A.Z[(int64_t)i * A.zs_i + (int64_t)j * A.zs_j + k]; continue; }
             double ex = D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k];
             if (A.Dm) // sum_s Ds x Ds = (D x D + M x M) / 2
                 ex += A.Dm[(size_t)i * ld + k] * A.Dm[(size_t)j * ld + l] + A.Dm[(size_t)i * ld + l] * A.Dm[(size_t)j * ld + k];
@@ -5264,9 +5272,9 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
             }
         }
     }
-    double w = 4.0;
+    double w = DF ? A.w0 : 4.0;
     if (dp.sh_i == dp.sh_j) w *= 0.5;
-    if (cd.sh_i == cd.sh_j) w *= 0.5;
+    if (!DF && cd.sh_i == cd.sh_j) w *= 0.5;
     if (same_pair) w *= 0.5;
     for (int x = 0; x < 3; x++) {
         double v = acc[x];
@@ -5274,8 +5282,10 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
         if (live && (lane & ((GSZ < 64 ? GSZ : 64) - 1)) == 0) { // one partial sum per wave (per 16-lane group for GSZ = 16)
             double *gc = A.grad + (size_t)((blockIdx.x * QPW + grp) & (GRAD_COPIES - 1)) * A.natm3;
             atomicAdd(&gc[A.shell_atom[dp.sh_i] * 3 + x], w * v);
-            // the skipped permutation (derivative on the first shell of the bra pair P) by invariance
-            atomicAdd(&gc[A.shell_atom[A.inv_from_second ? dp.sh_j : cd.sh_i] * 3 + x], -w * v);
+            // the skipped permutation (derivative on the first shell of the bra pair P) by invariance; density fitting:
+            // the auxiliary centre takes minus the force on the differentiated orbital (or auxiliary) shell
+            const int other = DF ? A.ket_atom[cd.sh_i] : A.shell_atom[A.inv_from_second ? dp.sh_j : cd.sh_i];
+            atomicAdd(&gc[other * 3 + x], -w * v);
         }
     }
 }
@@ -5867,6 +5877,258 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
     if (d_sh_ao) hipFree(d_sh_ao);
     if (d_sh_n) hipFree(d_sh_n);
     return 0;
+}
+
+// =================================================================================================
+// Nuclear gradient of the density-fitted two-electron energy (`mf.density_fit().nuc_grad_method()`
+// is PySCF idiom [MEM], the reference never calls it):
+//
+//   grad_X += sum_{ab,P} Z3[a][b][P] d/dX (ab|P)  +  sum_{PQ} Z2[P][Q] d/dX (P|Q)
+//
+// Z3 (symmetric in ab) and Z2 (symmetric) are the three- and two-index densities the host forms from the fitted tensor
+// (python/mi355scf/df.py: Z3 = c_P D_ab - hyb/2 Gamma^P_ab, Z2 = -c c^T / 2 + hyb/4 C.Gamma).  The derivative integrals go
+// through the SAME Rys kernel and contraction kernel as the four-centre gradient: the differentiated pair is an orbital pair
+// (either shell: two launches) or an auxiliary "pair" (P, unit function), its (l+1) / (l-1) variants carry 2 alpha c / c, the
+// ket is an auxiliary pair, and the force on the auxiliary centre follows from translational invariance (minus the force on
+// the differentiated shell).  Batches are dealt round-robin to `nranks` callers; the caller sums the partial gradients.
+// =================================================================================================
+extern "C" int mi_df_grad(mi_ctx *c, mi_ctx *aux, const double *d_Z3, const double *d_Z2, double *d_grad, int rank, int nranks, void *stream)
+{
+    if (!c || !aux || !d_grad) return fail("mi_df_grad: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("mi_df_grad: bad rank/nranks");
+    if (aux->nbas < 2) return fail("mi_df_grad: the auxiliary context needs at least one function plus the unit shell");
+    if (aux->natm != c->natm) return fail("mi_df_grad: orbital and auxiliary contexts must share the atom list");
+    const ShellH &U = aux->shells.back();
+    if (U.l != 0 || U.nprim != 1 || U.exps[0] != 0.0) return fail("mi_df_grad: the last auxiliary shell must be the unit s function (exponent 0)");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int naux = aux->nao - 1, unit_ao = aux->nao - 1, nP = aux->nbas - 1, nao = c->nao;
+    std::vector<std::vector<double>> c2s(LMAX + 1);
+    for (int l = 0; l <= LMAX; l++) c2s_generic(l, c2s[l]);
+    std::vector<double> prim, Mbuf;
+    // variant records: orbital pairs [class][orientation][l+1 | l-1] (parallel arrays), auxiliary pairs [l][l+1 | l-1]; plain auxiliary kets [l]
+    std::vector<PairRec> orb[NPC][2][2], axv[LMAX + 1][2], axk[LMAX + 1];
+    // pass 1 (serial): offsets of every variant record; pass 2 (OpenMP): primitive records and HRR x derivative x c2s matrices
+    struct Job { const ShellH *I, *J; PairRec *R; int sign; };
+    std::vector<Job> jobs;
+    size_t prim_end = 0, m_end = 0;
+    auto add_variant = [&](const ShellH &I, const ShellH &J, int s1, int s2, int ao1, int ao2, int sign, PairRec &R) {
+        double r2 = 0.0;
+        for (int d = 0; d < 3; d++) r2 += (I.r[d] - J.r[d]) * (I.r[d] - J.r[d]);
+        int np = 0;
+        for (int ip = 0; ip < I.nprim; ip++)
+            for (int jp = 0; jp < J.nprim; jp++)
+                if (I.exps[ip] * J.exps[jp] / (I.exps[ip] + J.exps[jp]) * r2 <= 80.0) np++;
+        R = PairRec{s1, s2, ao1, ao2, (int)prim_end, np, (int)m_end, 0};
+        prim_end += np;
+        m_end += (size_t)3 * (2 * I.l + 1) * (2 * J.l + 1) * ne_of(I.l + sign, J.l);
+    };
+    auto fill_variant = [&](const Job &jb) {
+        const ShellH &I = *jb.I, &J = *jb.J;
+        double AB[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+        double r2 = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
+        double *dst = prim.data() + (size_t)jb.R->prim_off * 8;
+        for (int ip = 0; ip < I.nprim; ip++)
+            for (int jp = 0; jp < J.nprim; jp++) {
+                double a = I.exps[ip], b = J.exps[jp], p = a + b, mu = a * b / p;
+                if (mu * r2 > 80.0) continue;
+                double K = I.coef[ip] * J.coef[jp] * std::exp(-mu * r2) * (jb.sign > 0 ? 2.0 * a : 1.0), Pc[3];
+                for (int d = 0; d < 3; d++) Pc[d] = (a * I.r[d] + b * J.r[d]) / p;
+                double rec[8] = {p, Pc[0], Pc[1], Pc[2], Pc[0] - I.r[0], Pc[1] - I.r[1], Pc[2] - I.r[2], K};
+                memcpy(dst, rec, sizeof rec);
+                dst += 8;
+            }
+        build_M_deriv(I.l, J.l, jb.sign, AB, c2s[I.l], c2s[J.l], Mbuf.data() + jb.R->m_off);
+    };
+    if (d_Z3)
+        for (int A = 0; A < c->nbas; A++)
+            for (int B = 0; B <= A; B++) {
+                int si = A, sj = B;
+                if (c->shells[si].l < c->shells[sj].l) std::swap(si, sj);
+                const ShellH &I = c->shells[si], &J = c->shells[sj];
+                double r2 = 0.0;
+                for (int d = 0; d < 3; d++) r2 += (I.r[d] - J.r[d]) * (I.r[d] - J.r[d]);
+                bool any = false;
+                for (int ip = 0; ip < I.nprim && !any; ip++)
+                    for (int jp = 0; jp < J.nprim; jp++)
+                        if (I.exps[ip] * J.exps[jp] / (I.exps[ip] + J.exps[jp]) * r2 <= 80.0) { any = true; break; }
+                if (!any) continue;
+                const int q = pc_index(I.l, J.l);
+                for (int o = 0; o < 2; o++) {
+                    const ShellH &F = o == 0 ? I : J, &S = o == 0 ? J : I;
+                    const int s1 = o == 0 ? si : sj, s2 = o == 0 ? sj : si;
+                    for (int sg = 0; sg < 2; sg++) {
+                        PairRec R{-1, -1, 0, 0, 0, 0, 0, 0};
+                        if (F.l + (sg == 0 ? 1 : -1) >= 0) add_variant(F, S, s1, s2, F.ao_nat, S.ao_nat, sg == 0 ? +1 : -1, R);
+                        orb[q][o][sg].push_back(R);
+                    }
+                }
+            }
+    for (int Pn = 0; Pn < nP; Pn++) {
+        const ShellH &S = aux->shells[Pn];
+        for (int sg = 0; sg < 2; sg++) {
+            PairRec R{-1, -1, 0, 0, 0, 0, 0, 0};
+            if (S.l + (sg == 0 ? 1 : -1) >= 0) add_variant(S, U, Pn, aux->nbas - 1, S.ao_nat, unit_ao, sg == 0 ? +1 : -1, R);
+            axv[S.l][sg].push_back(R);
+        }
+        PairRec R{Pn, aux->nbas - 1, S.ao_nat, unit_ao, (int)prim_end, S.nprim, (int)m_end, 0};     // plain ket record (filled below)
+        prim_end += S.nprim;
+        m_end += (size_t)(2 * S.l + 1) * ncart(S.l);
+        axk[S.l].push_back(R);
+    }
+    if (m_end > (size_t)INT32_MAX || prim_end > (size_t)INT32_MAX) return fail("mi_df_grad: record buffers exceed 2^31 entries");
+    prim.resize(prim_end * 8);
+    Mbuf.resize(m_end);
+    for (int q = 0; q < NPC; q++)
+        for (int o = 0; o < 2; o++)
+            for (int sg = 0; sg < 2; sg++)
+                for (PairRec &R : orb[q][o][sg])
+                    if (R.sh_i >= 0) jobs.push_back({&c->shells[R.sh_i], &c->shells[R.sh_j], &R, sg == 0 ? +1 : -1});
+    for (int l = 0; l <= LMAX; l++)
+        for (int sg = 0; sg < 2; sg++)
+            for (PairRec &R : axv[l][sg])
+                if (R.sh_i >= 0) jobs.push_back({&aux->shells[R.sh_i], &U, &R, sg == 0 ? +1 : -1});
+#pragma omp parallel for schedule(dynamic, 64) num_threads(host_threads())
+    for (size_t q = 0; q < jobs.size(); q++) fill_variant(jobs[q]);
+    for (int l = 0; l <= LMAX; l++)
+        for (PairRec &R : axk[l]) {
+            const ShellH &S = aux->shells[R.sh_i];
+            for (int ip = 0; ip < S.nprim; ip++) {
+                double rec[8] = {S.exps[ip], S.r[0], S.r[1], S.r[2], 0.0, 0.0, 0.0, S.coef[ip] * U.coef[0]};
+                memcpy(prim.data() + ((size_t)R.prim_off + ip) * 8, rec, sizeof rec);
+            }
+            double AB[3] = {0.0, 0.0, 0.0};
+            build_M(S.l, 0, AB, c2s[S.l], c2s[0], Mbuf.data() + R.m_off);
+        }
+    std::vector<int> atom_o(c->nbas), atom_a(aux->nbas);
+    for (int i = 0; i < c->nbas; i++) atom_o[i] = c->shells[i].atom;
+    for (int i = 0; i < aux->nbas; i++) atom_a[i] = aux->shells[i].atom;
+    double *d_prim = nullptr, *d_M = nullptr, *d_wp = nullptr, *d_wm = nullptr, *d_gcopies = nullptr;
+    uint32_t *d_comp_p = nullptr, *d_comp_m = nullptr;
+    int64_t *d_prefix = nullptr;
+    int *d_atom_o = nullptr, *d_atom_a = nullptr;
+    PairRec *d_orb[NPC][2][2] = {}, *d_axv[LMAX + 1][2] = {}, *d_axk[LMAX + 1] = {};
+    if (upload(&d_prim, prim) || upload(&d_M, Mbuf) || upload(&d_atom_o, atom_o) || upload(&d_atom_a, atom_a)) return -1;
+    for (int q = 0; q < NPC; q++)
+        for (int o = 0; o < 2; o++)
+            for (int sg = 0; sg < 2; sg++)
+                if (!orb[q][o][sg].empty() && upload(&d_orb[q][o][sg], orb[q][o][sg])) return -1;
+    for (int l = 0; l <= LMAX; l++) {
+        for (int sg = 0; sg < 2; sg++)
+            if (!axv[l][sg].empty() && upload(&d_axv[l][sg], axv[l][sg])) return -1;
+        if (!axk[l].empty() && upload(&d_axk[l], axk[l])) return -1;
+    }
+    const size_t WORK_DOUBLES = (size_t)32 << 20;
+    HIPCHK(hipMalloc(&d_wp, sizeof(double) * WORK_DOUBLES));
+    HIPCHK(hipMalloc(&d_wm, sizeof(double) * WORK_DOUBLES));
+    HIPCHK(hipMalloc(&d_comp_p, sizeof(uint32_t) * 16384));
+    HIPCHK(hipMalloc(&d_comp_m, sizeof(uint32_t) * 16384));
+    const int natm3 = c->natm * 3;
+    HIPCHK(hipMalloc(&d_gcopies, sizeof(double) * (size_t)GRAD_COPIES * natm3));
+    HIPCHK(hipMemsetAsync(d_gcopies, 0, sizeof(double) * (size_t)GRAD_COPIES * natm3, st));
+    size_t prefix_cap = 0;
+    int64_t batch_counter = 0;
+    const bool dbg = getenv("MI355_DEBUG") != nullptr;
+    // one pass: differentiated pairs `dp`/`dm` (l1 first, l2 second) against the auxiliary kets of angular momentum lk
+    auto run = [&](const PairRec *dp, const PairRec *dm, int nbra, int l1, int l2, int lk, const double *Z, int64_t zs_i, int64_t zs_j,
+                   const int *bra_atom, double w0) -> int {
+        const int nket = (int)axk[lk].size();
+        if (nbra == 0 || nket == 0) return 0;
+        const auto tr0 = std::chrono::steady_clock::now();
+        std::vector<int64_t> prefix(nbra + 1);
+        for (int b = 0; b <= nbra; b++) prefix[b] = (int64_t)b * nket;
+        const int64_t ntask = prefix.back();
+        append_coarse_index(prefix);
+        if (prefix.size() > prefix_cap) {
+            if (d_prefix) hipFree(d_prefix);
+            prefix_cap = prefix.size() * 2;
+            HIPCHK(hipMalloc(&d_prefix, sizeof(int64_t) * prefix_cap));
+        }
+        HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
+        const bool has_m = l1 >= 1;
+        EriArgs Ep{}, Em{};
+        setup_eri_dims(Ep, l1 + 1, l2, lk, 0);
+        if (has_m) setup_eri_dims(Em, l1 - 1, l2, lk, 0);
+        std::vector<uint32_t> comp;
+        build_comp_table(l1 + 1, l2, lk, 0, comp);
+        if (comp.size() > 16384) return fail("component table too large");
+        HIPCHK(hipMemcpyAsync(d_comp_p, comp.data(), sizeof(uint32_t) * comp.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (has_m) {
+            build_comp_table(l1 - 1, l2, lk, 0, comp);
+            HIPCHK(hipMemcpyAsync(d_comp_m, comp.data(), sizeof(uint32_t) * comp.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        Ep.bra = dp; Ep.ket = d_axk[lk]; Ep.prim = d_prim; Ep.prefix = d_prefix; Ep.nbra = nbra; Ep.comp = d_comp_p; Ep.work = d_wp;
+        Ep.rys = c->rys; Ep.diag = 0;
+        if (has_m) { Em.bra = dm; Em.ket = d_axk[lk]; Em.prim = d_prim; Em.prefix = d_prefix; Em.nbra = nbra; Em.comp = d_comp_m; Em.work = d_wm;
+                     Em.rys = c->rys; Em.diag = 0; }
+        GradXfArgs X{};
+        X.dplus = dp; X.dminus = has_m ? dm : nullptr; X.ket = d_axk[lk]; X.Mbuf = d_M; X.prefix = d_prefix; X.nbra = nbra;
+        X.ne_p = ne_of(l1 + 1, l2); X.ne_m = has_m ? ne_of(l1 - 1, l2) : 0; X.nf = ncart(lk);
+        X.ns1 = 2 * l1 + 1; X.ns2 = 2 * l2 + 1; X.nscd = 2 * lk + 1; X.nsd = 1;
+        X.work_p = d_wp; X.work_m = d_wm; X.ncomp_p = Ep.ncomp; X.ncomp_m = has_m ? Em.ncomp : 0;
+        X.shell_atom = bra_atom; X.ket_atom = d_atom_a; X.grad = d_gcopies; X.natm3 = natm3;
+        X.Z = Z; X.zs_i = zs_i; X.zs_j = zs_j; X.w0 = w0;
+        const size_t shm = sizeof(double) * ((size_t)X.ne_p * X.nf + (size_t)X.ne_m * X.nf + (size_t)X.ns1 * X.ns2 * (X.nf + X.nscd));
+        if (shm > 160 * 1024) return fail("gradient contraction needs %zu bytes of LDS", shm);
+        int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / Ep.ncomp), (int64_t)1 << 22);
+        if (nranks > 1) per = std::min<int64_t>(per, std::max<int64_t>(1024, ntask / (8 * nranks)));
+        const bool mf = mfma_worthwhile(X.ns1 * X.ns2, X.nf, X.nscd) || mfma_worthwhile(X.ns1 * X.ns2, X.ne_p, X.nf) ||
+                        (has_m && mfma_worthwhile(X.ns1 * X.ns2, X.ne_m, X.nf));
+        for (int64_t t0 = 0; t0 < ntask; t0 += per) {
+            if ((int)((batch_counter++) % nranks) != rank) continue;
+            const int nb = (int)std::min<int64_t>(per, ntask - t0);
+            Ep.t0 = t0; Ep.ntask = nb;
+            if (launch_eri(c, Ep, nb, st)) return -1;
+            if (has_m) { Em.t0 = t0; Em.ntask = nb; if (launch_eri(c, Em, nb, st)) return -1; }
+            X.t0 = t0; X.nbatch = nb;
+            if (mf) {
+                if (shm > 64 * 1024)
+                    HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract<64, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                hipLaunchKernelGGL((eri_grad_contract<64, true, true>), dim3(nb), dim3(64), shm, st, X);
+            } else {
+                if (shm > 64 * 1024)
+                    HIPCHK(hipFuncSetAttribute((const void *)eri_grad_contract<64, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                hipLaunchKernelGGL((eri_grad_contract<64, false, true>), dim3(nb), dim3(64), shm, st, X);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        if (dbg)
+            fprintf(stderr, "[mi355] df_grad (%d %d|%d): %ld tasks, %.3f s\n", l1, l2, lk, (long)ntask,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count());
+        return 0;
+    };
+    int rc = 0;
+    if (d_Z3)   // sum_ab over canonical shell pairs: weight 2 (1 on the diagonal, halved in the kernel), both orientations
+        for (int la = 0; la <= LMAX && !rc; la++)
+            for (int lb = 0; lb <= la && !rc; lb++)
+                for (int o = 0; o < 2 && !rc; o++)
+                    for (int lk = 0; lk <= LMAX && !rc; lk++) {
+                        const int q = pc_index(la, lb);
+                        rc = run(d_orb[q][o][0], d_orb[q][o][1], (int)orb[q][o][0].size(), o == 0 ? la : lb, o == 0 ? lb : la, lk, d_Z3,
+                                 (int64_t)nao * naux, (int64_t)naux, d_atom_o, 2.0);
+                    }
+    if (d_Z2)   // every ordered pair (P, Q): +v on the centre of P, -v on the centre of Q
+        for (int lp = 0; lp <= LMAX && !rc; lp++)
+            for (int lk = 0; lk <= LMAX && !rc; lk++)
+                rc = run(d_axv[lp][0], d_axv[lp][1], (int)axv[lp][0].size(), lp, 0, lk, d_Z2, (int64_t)naux, 0, d_atom_a, 1.0);
+    if (!rc) {
+        hipLaunchKernelGGL(grad_reduce_copies_kernel, dim3((natm3 + 63) / 64), dim3(64), 0, st, d_gcopies, natm3, d_grad);
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    for (int q = 0; q < NPC; q++)
+        for (int o = 0; o < 2; o++)
+            for (int sg = 0; sg < 2; sg++) if (d_orb[q][o][sg]) hipFree(d_orb[q][o][sg]);
+    for (int l = 0; l <= LMAX; l++) {
+        for (int sg = 0; sg < 2; sg++) if (d_axv[l][sg]) hipFree(d_axv[l][sg]);
+        if (d_axk[l]) hipFree(d_axk[l]);
+    }
+    hipFree(d_prim); hipFree(d_M); hipFree(d_wp); hipFree(d_wm); hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_gcopies);
+    hipFree(d_atom_o); hipFree(d_atom_a);
+    if (d_prefix) hipFree(d_prefix);
+    return rc;
 }
 
 // =================================================================================================

@@ -14,6 +14,7 @@ momentum spanning the products of the orbital primitives (the idea of PySCF's `d
 parity with PySCF's fitted energies is UNPINNED), l_aux <= 4 (g auxiliary shells; the two-electron kernels take l <= 4, the Rys tables stop at 8 roots).
 """
 import math
+import time
 
 import numpy as np
 import torch
@@ -52,6 +53,59 @@ def even_tempered_aux(mol, beta=2.0):
     return out
 
 
+def tri_inv_lower(L, base=2048):
+    """L^-1 of a lower-triangular matrix by recursive 2 x 2 blocking: [[A, 0], [C, D]]^-1 = [[A^-1, 0], [-D^-1 C A^-1, D^-1]]
+    (GEMMs above `base` rows; rocBLAS' trsm fails to allocate its workspace for N ~ 6000 right-hand sides)."""
+    n = L.shape[0]
+    if n <= base:
+        return torch.linalg.solve_triangular(L, torch.eye(n, dtype=L.dtype, device=L.device), upper=False)
+    h = (n // 2 + 63) // 64 * 64
+    out = torch.zeros_like(L)
+    Ai = tri_inv_lower(L[:h, :h].contiguous(), base)
+    Di = tri_inv_lower(L[h:, h:].contiguous(), base)
+    out[:h, :h] = Ai
+    out[h:, h:] = Di
+    out[h:, :h] = -(Di @ (L[h:, :h] @ Ai))
+    return out
+
+
+def pivoted_cholesky(dm, rank, rtol=1e-10):
+    """L [N, rank] with dm ~ L L^T by `rank` steps of diagonally pivoted Cholesky (no host synchronisation inside the loop), or
+    None when the remainder is not negligible (dm is not a positive semi-definite matrix of that rank: a random test density,
+    a difference density).  An SCF density is 2 C_occ C_occ^T: rank = number of occupied orbitals."""
+    n = dm.shape[0]
+    rank = min(int(rank), n)
+    d = dm.diagonal().clone()
+    floor = (rtol * d.abs().max()).clamp_min(1e-300)       # pivots below it end the factorisation (columns of zeros: beta spin of
+    L = torch.zeros(n, rank, dtype=dm.dtype, device=dm.device)   # an open shell has fewer occupied orbitals than the hint)
+    zero = torch.zeros((), dtype=dm.dtype, device=dm.device)
+    for k in range(rank):
+        p = torch.argmax(d).reshape(1)
+        piv = d.index_select(0, p)
+        col = dm.index_select(1, p).squeeze(1)
+        if k:
+            col = col - L[:, :k] @ L.index_select(0, p)[0, :k]
+        col = torch.where(piv > floor, col * torch.rsqrt(piv.clamp_min(1e-300)), zero)
+        L[:, k] = col
+        d = d - col * col
+    if not bool(((dm - L @ L.t()).abs().max() <= floor).item()):          # the one synchronisation
+        return None
+    return L
+
+
+def _psd_factor(ds, rtol=1e-10):
+    """F [N, r] with Ds = F F^T for a (numerically) positive semi-definite spin density of low rank, or None when the
+    discarded part of the spectrum is not negligible (the caller then takes the dense route)."""
+    lam, V = torch.linalg.eigh(ds)
+    top = float(lam[-1])
+    if top <= 0.0:
+        return None
+    keep = lam > rtol * top
+    if float(lam[~keep].abs().max()) > 1e-9 * top if bool((~keep).any()) else False:
+        return None
+    return (V[:, keep] * lam[keep].sqrt()).contiguous()
+
+
 class DF:
     """Fitted three-index tensor of one molecule on one GPU."""
 
@@ -86,16 +140,19 @@ class DF:
             pass
         pk = _Packed()
         pk._atm, pk._bas, pk._env, pk.nao = aux._atm, bas, env, aux.nao + 1
+        self._aux_packed = pk
         aux_eng = _engine.Engine(pk, device=engine.device)
         n, na = mol.nao, self.naux
-        int3c = torch.empty(n, n, na, dtype=torch.float64, device=engine.device)
-        int2c = torch.empty(na, na, dtype=torch.float64, device=engine.device)
+        # zeros: shell pairs whose primitive products all vanish (exp(-80)) are skipped by mi_df_build, their blocks stay unwritten
+        int3c = torch.zeros(n, n, na, dtype=torch.float64, device=engine.device)
+        int2c = torch.zeros(na, na, dtype=torch.float64, device=engine.device)
         engine.df_build(aux_eng, int3c, int2c)
         aux_eng.close()
         self.int2c = int2c
+        self._nranks_built = nranks
         L = torch.linalg.cholesky(int2c)
         # fitted tensor B[i, P, j] = sum_Q L^-1[P, Q] (Q|ij), stored i-major: the exchange build is then two plain GEMMs
-        Linv = torch.linalg.solve_triangular(L, torch.eye(na, dtype=torch.float64, device=engine.device), upper=False)
+        Linv = tri_inv_lower(L)
         from .parallel import split_range
         p0, p1 = split_range(na, rank, nranks) if nranks > 1 else (0, na)
         self.aux_slice = (p0, p1)
@@ -129,10 +186,102 @@ class DF:
         if with_k:
             K = torch.zeros_like(dm)
             Bf = B.reshape(n, na * n)
+            hint = getattr(self, "rank_hint", None)
             for s_ in range(dm.shape[0]):
+                # SCF densities are low rank (occupied orbitals): K = sum_P (B^P L)(B^P L)^T costs 4 N^2 N_aux n_occ flops
+                # instead of 4 N^3 N_aux; `rank_hint` is set by the SCF driver, any other density takes the dense route
+                L = pivoted_cholesky(dm[s_], hint) if hint and 2 * hint <= n else None
+                if L is not None:
+                    Y = torch.matmul(B.reshape(n * na, n), L).reshape(n, na * L.shape[1])
+                    self._eng.xc_vmat(Y, Y, K[s_])                                # K += Y . Y^T
+                    self.k_path = "low rank"
+                    continue
+                self.k_path = "dense"
                 T = torch.matmul(B.reshape(n * na, n), dm[s_]).reshape(n, na * n)  # [i, (P, l)]
                 self._eng.xc_vmat(T, Bf, K[s_])                                   # K += T . Bf^T
         if squeeze:
             J = J[0] if J is not None else None
             K = K[0] if K is not None else None
         return J, K
+
+    def grad_jk(self, dms, hyb=1.0, rank=0, nranks=1, factorize=True):
+        """Nuclear gradient [natm, 3] (device tensor) of the fitted two-electron energy
+             E2 = 1/2 g^T V^-1 g - hyb/2 sum_s sum_PQ (ik|P) V^-1_PQ (Q|jl) Ds_ij Ds_kl,     g_P = sum_ij (ij|P) D_ij,
+        for the spin densities `dms` = [Da, Db] (closed shell: [D/2, D/2], or one [N,N] total density):
+             dE2 = sum_{ij,P} Z3[i,j,P] d(ij|P) + sum_PQ Z2[P,Q] d(P|Q),
+             Z3 = c_P D_ij - hyb sum_s Gs^P_ij,   Z2 = -1/2 c c^T + hyb/2 sum_s sum_ij C^P_ij Gs^Q_ij,
+             c = V^-1 g,  C^P = sum_Q V^-1_PQ (Q|ij) (fit coefficients),  Gs^P = Ds C^P Ds
+        (the idea of pyscf.df.grad.rhf.get_jk [MEM]).  With the whitened tensor B = L^-1 (Q|ij) (V = L L^T): C = L^-T B,
+        Gs = L^-T Ws, Ws^P = Ds B^P Ds, so everything is GEMMs on B plus two triangular back-transformations; the derivative
+        integrals themselves are contracted on the fly by `mi_df_grad` (no derivative tensor is stored).  Needs the whole
+        auxiliary index on this rank (a sharded tensor is rebuilt whole by the caller); `rank`/`nranks` deal the
+        derivative-integral batches, the caller sums the partial gradients."""
+        if self._B is None or getattr(self, "_nranks_built", 1) != 1:
+            raise RuntimeError("DF.grad_jk needs the unsharded fitted tensor: call build(engine) first")
+        eng, B = self._eng, self._B
+        n, na, _ = B.shape
+        dev = B.device
+        t0 = time.time()
+        if torch.is_tensor(dms) and dms.dim() == 2:
+            dms = [0.5 * dms, 0.5 * dms]
+        dms = [torch.as_tensor(d, dtype=torch.float64, device=dev).contiguous() for d in dms]
+        closed = len(dms) == 2 and (dms[0] is dms[1] or torch.equal(dms[0], dms[1]))
+        D = dms[0] + dms[1] if len(dms) == 2 else dms[0]
+        L = torch.linalg.cholesky(self.int2c)
+        Linv = tri_inv_lower(L)                                                                                # [P', Q]
+        rho = torch.einsum("ipj,ij->p", B, D)                                                                  # whitened g
+        c = Linv.t() @ rho                                                                                     # V^-1 g
+        # three-index density in the layout the kernel reads, Z3[i, j, Q]
+        Z3 = torch.empty(n, n, na, dtype=torch.float64, device=dev)
+        Z2 = -0.5 * torch.outer(c, c)
+        if hyb != 0.0:
+            factors = [_psd_factor(ds) for ds in (dms[:1] if closed else dms)] if factorize else None
+            if factors is not None and all(f is not None for f in factors):
+                # Ds = Fs Fs^T (rank = occupied orbitals): everything through X_s[o, P, o'] = Fs^T B^P Fs, 2 N^2 N_aux n_occ flops
+                # where the dense route below costs 2 N^2 N_aux^2
+                Z3.zero_()
+                for F in factors:
+                    no = F.shape[1]
+                    Y = torch.matmul(B.reshape(n * na, n), F).reshape(n, na * no)              # Y[i, (P', o')]
+                    X = torch.matmul(F.t(), Y).reshape(no, na, no)                             # X[o, P', o']
+                    del Y
+                    Xt = torch.einsum("pq,opr->oqr", Linv, X).contiguous()                     # back-transformed over the auxiliary index
+                    Xm = Xt.permute(1, 0, 2).reshape(na, no * no)
+                    Z2 += (1.0 if closed else 0.5) * hyb * (Xm @ Xm.t())
+                    U = torch.matmul(F, Xt.reshape(no, na * no)).reshape(n, na, no)             # U[i, Q, o']
+                    step = max(1, int(2.0e9 / (8.0 * na * n)))
+                    for i0 in range(0, n, step):      # Z3[i, k, Q] -= hyb sum_o' F[k, o'] U[i, Q, o']
+                        Z3[i0:i0 + step].add_(torch.matmul(F, U[i0:i0 + step].transpose(1, 2)), alpha=-(2.0 if closed else 1.0) * hyb)
+                    del U, X, Xt, Xm
+            else:
+                BW = torch.zeros(na, na, dtype=torch.float64, device=dev)
+                W = torch.zeros(n, na, n, dtype=torch.float64, device=dev)
+                for ds in (dms[:1] if closed else dms):
+                    T = torch.matmul(B.reshape(n * na, n), ds).reshape(n, na * n)          # T[j, (P, k)] = sum_l B[j, P, l] Ds[l, k]
+                    W += torch.matmul(ds, T).reshape(n, na, n)                              # Ws[i, P, k] = sum_j Ds[i, j] T[j, P, k]
+                    del T
+                if closed:
+                    W *= 2.0
+                # sum_ik B[i, P, k] W[i, R, k]  (whitened indices), then back-transformed on both sides
+                step = max(1, int(2.0e9 / (8.0 * na * n)))
+                for i0 in range(0, n, step):
+                    BW += torch.einsum("ipk,irk->pr", B[i0:i0 + step], W[i0:i0 + step])
+                Z2 += 0.5 * hyb * (Linv.t() @ BW @ Linv)
+                for i0 in range(0, n, step):      # Z3[i, k, Q] = -hyb sum_P' W[i, P', k] Linv[P', Q]
+                    torch.matmul(W[i0:i0 + step].transpose(1, 2), Linv, out=Z3[i0:i0 + step])
+                Z3 *= -hyb
+                del W
+            Z3 += D.unsqueeze(2) * c.view(1, 1, na)
+        else:
+            Z3.copy_(D.unsqueeze(2) * c.view(1, 1, na))
+        Z2 = (0.5 * (Z2 + Z2.t())).contiguous()      # Z3 is symmetric in (i, j) by construction (B^P, Ds symmetric)
+        aux_eng = _engine.Engine(self._aux_packed, device=dev)
+        g = torch.zeros(len(eng._atm), 3, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        t1 = time.time()
+        try:
+            eng.df_grad(aux_eng, Z3, Z2, g, rank=rank, nranks=nranks)
+        finally:
+            aux_eng.close()
+        self.grad_timing = {"densities": t1 - t0, "derivative_integrals": time.time() - t1}
+        return g

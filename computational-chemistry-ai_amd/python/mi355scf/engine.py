@@ -111,6 +111,7 @@ def lib():
         L.mi_eri_read_quartet.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
         L.mi_schwarz_get.argtypes = [vp, dp]
         L.mi_df_build.argtypes = [vp, vp, vp, vp, vp]
+        L.mi_df_grad.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]
         L.mi_reduce_blocks.argtypes = [vp]
         L.mi_plan_shards.argtypes = [ctypes.c_int, dp, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
                                      ctypes.POINTER(ctypes.c_int64)]
@@ -297,6 +298,22 @@ class Engine:
         with torch.cuda.device(self.device):
             _check(lib().mi_df_build(self._h, aux_engine._h, int3c.data_ptr() if int3c is not None else None,
                                      int2c.data_ptr() if int2c is not None else None, self._stream()))
+
+    def df_grad(self, aux_engine, z3, z2, grad, rank=0, nranks=1):
+        """grad[natm, 3] += sum Z3[a, b, P] d(ab|P)/dX + sum Z2[P, Q] d(P|Q)/dX (this rank's share of the batches)."""
+        for t in (z3, z2):
+            if t is not None and not (t.is_contiguous() and t.dtype == torch.float64 and t.device == self.device):
+                raise ValueError("df_grad: contiguous float64 tensors on the engine's device are required")
+        n, na = self.nao, aux_engine.nao - 1
+        if z3 is not None and tuple(z3.shape) != (n, n, na):
+            raise ValueError(f"df_grad: Z3 must be [{n}, {n}, {na}]")
+        if z2 is not None and tuple(z2.shape) != (na, na):
+            raise ValueError(f"df_grad: Z2 must be [{na}, {na}]")
+        if tuple(grad.shape) != (len(self._atm), 3) or not grad.is_contiguous() or grad.dtype != torch.float64:
+            raise ValueError("df_grad: grad must be a contiguous float64 [natm, 3] tensor")
+        with torch.cuda.device(self.device):
+            _check(lib().mi_df_grad(self._h, aux_engine._h, z3.data_ptr() if z3 is not None else None,
+                                    z2.data_ptr() if z2 is not None else None, grad.data_ptr(), int(rank), int(nranks), self._stream()))
 
     def eri_dense(self):
         """(ij|kl) as a dense [nao]*4 device tensor (small molecules only: 8 nao^4 bytes)."""

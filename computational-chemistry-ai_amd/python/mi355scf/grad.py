@@ -79,8 +79,6 @@ class Gradients:
 
     def kernel(self, mo_energy=None, mo_coeff=None, mo_occ=None, atmlst=None):
         mf = self.base
-        if getattr(mf, "with_df", None) is not None:
-            raise NotImplementedError("analytic gradients of density-fitted SCF are not implemented (use the exact-integral SCF)")
         if mf._dm is None or not mf.converged:
             mf.kernel()
         eng = mf.engine
@@ -101,8 +99,11 @@ class Gradients:
             from .dft import parse_xc
             hyb = parse_xc(mf.xc)[0]
         t0 = time.time()
-        g2 = torch.zeros_like(g)
-        eng.grad_eri(dm.contiguous(), hyb, g2, rank=mf._rank, nranks=mf._nranks)
+        if getattr(mf, "with_df", None) is not None:
+            g2 = _fitted_tensor(mf).grad_jk(dm, hyb, rank=mf._rank, nranks=mf._nranks)
+        else:
+            g2 = torch.zeros_like(g)
+            eng.grad_eri(dm.contiguous(), hyb, g2, rank=mf._rank, nranks=mf._nranks)
         tm["grad_eri"] = time.time() - t0
         if mf._nranks > 1:   # derivative-quartet batches are dealt round-robin to ranks inside mi_grad_eri
             from . import parallel
@@ -133,6 +134,16 @@ class Gradients:
         return _GradScanner(self)
 
 
+def _fitted_tensor(mf):
+    """The fitted tensor with the WHOLE auxiliary index on this rank: `mf.with_df` itself, or (sharded run: every rank holds a
+    slice of the whitened index, and the exchange part of the two-index density couples all slices) one rebuilt here."""
+    d = mf.with_df
+    if getattr(d, "_nranks_built", 1) == 1 and d._B is not None:
+        return d
+    from .df import DF
+    return DF(mf.mol, d.auxbasis, d.beta).build(mf.engine)
+
+
 class UGradients(Gradients):
     """Analytic UHF gradient: the restricted pieces with D = Da + Db, W = sum_s Ds Fs Ds, and the exchange part of
     the two-particle density from both spins (`mi_grad_eri_spin`, spin density M = Da - Db)."""
@@ -155,8 +166,11 @@ class UGradients(Gradients):
         if is_ks:
             from .dft import parse_xc
             hyb = parse_xc(mf.xc)[0]
-        g2 = torch.zeros_like(g)
-        eng.grad_eri(D, hyb, g2, spin_density=M, rank=mf._rank, nranks=mf._nranks)
+        if getattr(mf, "with_df", None) is not None:
+            g2 = _fitted_tensor(mf).grad_jk([dma, dmb], hyb, rank=mf._rank, nranks=mf._nranks)
+        else:
+            g2 = torch.zeros_like(g)
+            eng.grad_eri(D, hyb, g2, spin_density=M, rank=mf._rank, nranks=mf._nranks)
         if mf._nranks > 1:
             from . import parallel
             parallel.all_reduce_sum(g2, mf._pg)

@@ -295,6 +295,8 @@ class SCF:
                 self.with_df.mol = self.mol
                 t1 = time.time()
                 self.with_df.build(eng, self._rank, self._nranks)
+                # SCF densities have the rank of the occupied space: the exchange build factorises them (df.pivoted_cholesky)
+                self.with_df.rank_hint = (int(self.mol.nelectron) + int(getattr(self.mol, "spin", 0))) // 2
                 torch.cuda.synchronize()
                 self.timing["df_seconds"] = time.time() - t1
                 self._log(4, f"density fitting: {self.with_df.naux} auxiliary functions, tensor "

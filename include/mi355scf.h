@@ -105,6 +105,14 @@ int mi_plan_shards(int nao, const double *qblk, double tol, int nranks, int64_t 
  * mi_ctx_nao(aux) - 1; either may be NULL.  Replaces libcint int3c2e_sph / int2c2e_sph behind pyscf.df [MEM]. */
 int mi_df_build(mi_ctx *ctx, mi_ctx *aux, double *d_int3c, double *d_int2c, void *stream);
 
+/* Nuclear gradient of the fitted two-electron energy: d_grad[natm][3] += sum_{ab,P} Z3[a][b][P] d(ab|P)/dX
+ * + sum_{PQ} Z2[P][Q] d(P|Q)/dX, with the three-index density d_Z3[nao][nao][naux] (symmetric in ab) and the two-index density
+ * d_Z2[naux][naux] (symmetric) formed by the caller from the fitted tensor (either may be NULL).  `aux` as in mi_df_build (same
+ * atom list as ctx).  The derivative-integral batches are dealt round-robin to `nranks` callers (rank 0 of 1: everything);
+ * the caller adds the partial gradients.  Replaces libcint int3c2e_ip1 / int3c2e_ip2 / int2c2e_ip1 behind
+ * pyscf.df.grad.rhf.get_jk [MEM] (`mf.density_fit().nuc_grad_method()`; the reference never calls it). */
+int mi_df_grad(mi_ctx *ctx, mi_ctx *aux, const double *d_Z3, const double *d_Z2, double *d_grad, int rank, int nranks, void *stream);
+
 /* Schwarz factors of the last mi_eri_prepare: q[nbas][nbas] (host), q_ab = sqrt(max |(ab|ab)|), 0 for dropped pairs.
  * Replaces: libcvhf CVHFnr_int2e_q_cond [MEM]. */
 int mi_schwarz_get(const mi_ctx *ctx, double *q);

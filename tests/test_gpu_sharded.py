@@ -4,6 +4,7 @@ Energies must equal the unsharded run; tile shards must be disjoint and exhausti
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
@@ -60,9 +61,7 @@ def _worker_body(rank, world, port, method, q, opts):
         st = {k: sum(g[k] for g in gs.values()) for k in ("n_tiles", "n_unique_eri")}
     if opts.get("df"):
         st = {"n_tiles": int(mf.with_df._B.shape[1]), "n_unique_eri": int(mf.with_df.naux)}   # this rank's auxiliary slice
-        g = np.zeros((mol.natm, 3))
-    else:
-        g = mf.nuc_grad_method().kernel()
+    g = mf.nuc_grad_method().kernel()
     q.put((rank, e, bool(mf.converged), st["n_tiles"], st["n_unique_eri"], g.tolist(), coll, float(e).hex()))
     import torch.distributed as dist
     dist.destroy_process_group()
@@ -282,7 +281,8 @@ def test_direct_mode_gradient_matches_resident():
 
 def test_two_rank_density_fitting_shards_the_auxiliary_index():
     """`mf.density_fit()` on two ranks: each keeps half of the whitened auxiliary index of B[i,P,j]; partial J / K are summed by
-    the one Fock all-reduce; the energy equals the single-rank fitted energy."""
+    the one Fock all-reduce; the energy equals the single-rank fitted energy.  The gradient of the fitted energy deals the
+    derivative-integral batches to the two ranks (each on a whole fitted tensor rebuilt for it) and sums them."""
     from pyscf import gto, scf
     mol = gto.Mole()
     mol.atom = MOLECULES["h2co"]
@@ -292,6 +292,7 @@ def test_two_rank_density_fitting_shards_the_auxiliary_index():
     mf = scf.RHF(mol).density_fit()
     mf.conv_tol = 1e-10
     e1 = mf.kernel()
+    g1 = mf.nuc_grad_method().kernel()
     naux = mf.with_df.naux
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -309,3 +310,4 @@ def test_two_rank_density_fitting_shards_the_auxiliary_index():
     assert res[0][3] + res[1][3] == naux and min(res[0][3], res[1][3]) > 0 and res[0][4] == naux
     for r in res:
         assert r[6]["all_reduce"] == r[6]["fock_builds"], r[6]
+        assert np.abs(np.array(r[5]) - g1).max() < 1e-8 and np.abs(g1).max() > 1e-3
