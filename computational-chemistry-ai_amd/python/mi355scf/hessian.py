@@ -3,8 +3,10 @@ section 8f rank 4; call sites `templates/optimize_geometry.py:117-123` (`hessian
 and `templates/opt-freq.py:392-417` (`gpu_hessian.rks.Hessian(mf_opt).kernel()`, `hessian.rks.Hessian(mf_cpu)`)).
 
 Semi-numerical: central finite differences of the ANALYTIC gradient (HIP derivative-integral kernels, `grad.py`), one SCF +
-gradient per displaced geometry (6 N_atom in total, each SCF warm-started from the reference density).  Analytic second
-derivatives (CPHF) are not implemented.  Returns the PySCF layout `hess[i, j, x, y] = d2E / dR_ix dR_jy` (Hartree/Bohr^2).
+gradient per displaced geometry (6 N_atom in total).  ONE working object is moved through all displaced geometries by the
+gradient scanner (`mf.reset(mol)`: the resident tile store, the library handles and the purification plans are reused -- a
+fresh object per point would allocate its own store, 100 GB for ibuprofen/def2-TZVP), each SCF starts from the density of
+the point before.  Analytic second derivatives (CPHF) are not implemented.  Returns the PySCF layout `hess[i, j, x, y] = d2E / dR_ix dR_jy` (Hartree/Bohr^2).
 """
 import numpy as np
 
@@ -45,19 +47,24 @@ class Hessian:
         H = np.zeros((n, 3, n, 3))
         dmu = np.zeros((n, 3, 3))          # d mu_c / d R_ix (a.u.), by-product of the same displaced SCFs (IR intensities)
         h = self.step
+        work = self._clone_at(R)
+        if getattr(mf, "with_df", None) is not None:
+            work = work.density_fit(mf.with_df.auxbasis)
+        if getattr(mf, "_nranks", 1) > 1:
+            work.shard(mf._rank, mf._nranks, getattr(mf, "_pg", None))
+        work.kernel(dm0=dm0)
+        scan = work.nuc_grad_method().as_scanner()
         for ia in range(n):
             for x in range(3):
                 g, mu = [], []
                 for sgn in (+1.0, -1.0):
                     Rd = R.copy()
                     Rd[ia, x] += sgn * h
-                    c = self._clone_at(Rd)
-                    c.kernel(dm0=dm0)
-                    if not c.converged:
+                    _e, de = scan(Rd)
+                    if not scan.converged:
                         raise RuntimeError("SCF did not converge at a displaced geometry of the Hessian")
-                    g.append(c.nuc_grad_method().kernel())
-                    mu.append(np.asarray(c.dip_moment(unit="au")))
-                    c._eng = None
+                    g.append(np.array(de))
+                    mu.append(np.asarray(work.dip_moment(unit="au")))
                 H[ia, x] = (g[0] - g[1]) / (2.0 * h)
                 dmu[ia, x] = (mu[0] - mu[1]) / (2.0 * h)
             mf._log(4, f"Hessian: atom {ia + 1}/{n} done")
