@@ -325,7 +325,6 @@ struct mi_ctx {
     int opt_tri_tiles = 1;   // block-diagonal tiles store triangular rows (0: the full-row layout of round 1); next mi_eri_prepare
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
-    int opt_jk_split = 0;    // J+K: j rows of a tile split between two waves (jk_tiles_split_kernel), two waves per SIMD, experiment
     int opt_jk_kjlt = 0;     // J+K: K_JL reduced per tile instead of run-wide accumulators (two waves per SIMD), experiment
     int opt_jk_dpp = 1;      // per-tile reduce-scatters of the J/K kernel through DPP moves (0: ds_bpermute, the round-1/2 path)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
@@ -580,7 +579,6 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else if (k == "jk_dpp") c->opt_jk_dpp = (int)value;
     else if (k == "jk_kjlt") c->opt_jk_kjlt = (int)value;
-    else if (k == "jk_split") c->opt_jk_split = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
     else if (k == "jk_pair") c->opt_jk_pair = (int)value;
     else if (k == "sp2_persist") c->opt_sp2_persist = (int)value;
@@ -2838,6 +2836,11 @@ __device__ __forceinline__ d2_t jk_load_chunk(const d2_t *__restrict__ tile, int
 // help (498 registers, 2.19 ms).  For the Coulomb-only build the same specialisation is harmless but its gain (0.742 vs 0.754-0.772
 // ms on one box, 0.770 vs 0.768-0.772 on another; +8 % on the cache-resident cc-pVDZ tensor) is within box-to-box noise: not kept.
 // Any rewrite has to bound the loads in flight by construction.
+// Row split (round 3, measured and removed; commit "Experiment: J+K digestion with the j rows of a tile split between two waves"):
+// a workgroup of two waves, wave w owning T[i, 4w..4w+3, k, :], 32 K_JL accumulators and partial K_IK / K_IL sums merged through
+// LDS (one barrier per tile), fits 256 registers (two waves per SIMD, 132 bytes of scratch) and gives the same J, K, but every
+// per-tile fixed cost (density rows, reduce-scatters, directory reads) is paid by both waves: 1.14 ms with the LDS merge, 1.21 ms
+// with both waves issuing their own atomics, against 0.86 ms for the one-wave kernel on the same box (benzene/cc-pVTZ).
 // KJLT (round 3): K_JL is reduced over the 64 lanes PER TILE (8 DPP reduce-scatters over the k-lanes while the rows stream in,
 // one reduce-scatter over the i-lanes, one more 512-byte atomic) instead of living in 64 run-wide accumulators per lane: 128
 // registers less, which is what keeps the K-carrying kernel at one wave per SIMD.
@@ -3030,174 +3033,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         else jk_segment<true, true, NT, false, true>(A, seg);
     }
 }
-// J+K with the j rows of every tile split between the TWO waves of a workgroup (jk_split option, round 3).  The one-wave kernel
-// above needs 256 VGPRs + 158 AGPRs (128 of them the run-wide K_JL accumulators): one wave per SIMD, and ~260 of its ~1 400
-// instructions per tile are v_accvgpr moves of accumulators parked in AGPRs.  Here wave w owns T[i, 4w..4w+3, k, :] (16 of the
-// 32 chunks of a tile, rows 16 w .. 16 w + 15: 16 KB contiguous), 32 K_JL accumulators, its half of J_IJ / K_JK, and partial
-// K_IK / K_IL / J_KL sums over its j rows: the budget of 256 registers admits two waves per SIMD.  The two partial per-tile
-// blocks (K_IK, K_IL) are merged through LDS (wave 1 writes 16 bytes per lane into one of two slots, one barrier per tile, wave 0
-// adds and issues the atomics), so the atomic traffic per tile is the same three 512-byte blocks as before.
-template <bool NT, bool DIJ, bool DKL, int VAR>
-__device__ __forceinline__ void jk_digest_half(const JkArgs &A, const int lane, const int i, const int k, const int w, const int I0,
-                                               const int J0, const int K0, const int L0, const int ld, const int bk, const int64_t toff,
-                                               const double (&dKL)[8], const double (&dJK)[4], double (&kjl)[4][8], double (&jkl)[8],
-                                               double (&kjk)[4], d2_t *slot)
-{
-    const double *__restrict__ D = A.D;
-    const MI_CONST_AS double *Du = as_const(A.D);
-    const int bi = min(BLK, A.nao - I0);
-    const bool active = (i < bi) && (k < bk);
-    const d2_t *__restrict__ T = reinterpret_cast<const d2_t *>(A.tiles + toff);
-    double dIJ[4], dIL[8];
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) dIJ[jj] = D[(size_t)(I0 + i) * ld + J0 + 4 * w + jj];
-#pragma unroll
-    for (int l = 0; l < 8; l++) dIL[l] = D[(size_t)(I0 + i) * ld + L0 + l];
-    const double dIK = D[(size_t)(I0 + i) * ld + K0 + k];
-    double kik = 0.0, jij[4], kil[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) kil[j] = 0.0;
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) jij[jj] = 0.0;
-    // rows are streamed one ahead (4 chunks = 16 registers in flight beside the row being contracted); the scheduling barriers
-    // keep the compiler from hoisting all 16 chunk loads of the half tile (and the next tile's) above the arithmetic, which
-    // costs 100 registers of scratch at this budget -- the second wave of the SIMD is what hides the latency here
-    d2_t cur[4], nxt[4];
-#pragma unroll
-    for (int lp = 0; lp < 4; lp++) cur[lp] = jk_load_chunk<DIJ, DKL, NT>(T, 4 * w, lp, bi, bk, i, k, active);
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) {
-        const int j = 4 * w + jj;
-        if (jj < 3) {
-#pragma unroll
-            for (int lp = 0; lp < 4; lp++) nxt[lp] = jk_load_chunk<DIJ, DKL, NT>(T, j + 1, lp, bi, bk, i, k, active);
-        }
-        if (VAR & 1) __builtin_amdgcn_sched_barrier(0);
-        const MI_CONST_AS double *dJL = Du + (size_t)(J0 + j) * ld + L0; // wave-uniform row (SGPRs)
-#pragma unroll
-        for (int l = 0; l < 8; l++) {
-            const double x = (l & 1) ? cur[l >> 1].y : cur[l >> 1].x;
-            kik = fma(x, dJL[l], kik);
-            kil[l] = fma(x, dJK[jj], kil[l]);
-            kjl[jj][l] = fma(x, dIK, kjl[jj][l]);
-            kjk[jj] = fma(x, dIL[l], kjk[jj]);
-            jij[jj] = fma(x, dKL[l], jij[jj]);
-            jkl[l] = fma(x, dIJ[jj], jkl[l]);
-        }
-        if (VAR & 1) __builtin_amdgcn_sched_barrier(0);
-        if (jj < 3) {
-#pragma unroll
-            for (int lp = 0; lp < 4; lp++) cur[lp] = nxt[lp];
-        }
-    }
-    const double r_kil = reduce8_low(kil, lane);   // lane holds l = k (partial over this wave's j rows)
-    // four values over the 8 k-lanes: all-reduce over lane bit 2 (row_half_mirror pairs lanes of opposite bit 2), then a
-    // reduce-scatter over bits 1 and 0: every lane holds j = 4 w + (k & 3), lanes k < 4 add it
-    double r_jij;
-    {
-        constexpr int HALF_MIRROR = 0x141, QP_XOR2 = 0x4E, QP_XOR1 = 0xB1;
-        double a4[4], b2[2];
-        const bool h1 = lane & 2, h0 = lane & 1;
-#pragma unroll
-        for (int t = 0; t < 4; t++) a4[t] = jij[t] + dpp_move<HALF_MIRROR>(jij[t]);
-#pragma unroll
-        for (int t = 0; t < 2; t++) b2[t] = (h1 ? a4[t + 2] : a4[t]) + dpp_move<QP_XOR2>(h1 ? a4[t] : a4[t + 2]);
-        r_jij = (h0 ? b2[1] : b2[0]) + dpp_move<QP_XOR1>(h0 ? b2[0] : b2[1]);
-    }
-    if (VAR & 2) {
-        if (w == 1) { d2_t o = {kik, r_kil}; slot[lane] = o; }
-        __syncthreads();
-        if (w == 0) {
-            const d2_t o = slot[lane];
-            atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik + o.x);
-            atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + L0 + k], r_kil + o.y);
-        }
-    } else {
-        atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + K0 + k], kik);
-        atomicAdd(&A.Kacc[(size_t)(I0 + i) * ld + L0 + k], r_kil);
-    }
-    if (k < 4) atomicAdd(&A.Jacc[(size_t)(I0 + i) * ld + J0 + 4 * w + k], r_jij);
-}
-
-template <bool NT, int VAR>
-__device__ __forceinline__ void jk_segment_split(const JkArgs &A, const int seg, d2_t *lds)
-{
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index: scalar
-    const int i = lane >> 3, k = lane & 7;
-    const MI_CONST_AS int *tile_I = as_const(A.tile_I);
-    const MI_CONST_AS int64_t *tile_off = as_const(A.tile_off);
-    const MI_CONST_AS RunRec *rr = as_const(A.runs) + seg;
-    const RunRec R{rr->J, rr->K, rr->L, rr->first, rr->count};
-    const int J0 = R.J * BLK, K0 = R.K * BLK, L0 = R.L * BLK;
-    const int ld = A.ld;
-    const int bk = min(BLK, A.nao - K0);
-    const double *__restrict__ D = A.D;
-    double dKL[8], dJK[4];
-#pragma unroll
-    for (int l = 0; l < 8; l++) dKL[l] = D[(size_t)(K0 + k) * ld + L0 + l];
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) dJK[jj] = D[(size_t)(J0 + 4 * w + jj) * ld + K0 + k];
-    double kjl[4][8], jkl[8], kjk[4];
-#pragma unroll
-    for (int l = 0; l < 8; l++) jkl[l] = 0.0;
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) {
-        kjk[jj] = 0.0;
-#pragma unroll
-        for (int l = 0; l < 8; l++) kjl[jj][l] = 0.0;
-    }
-    int I_next = tile_I[R.first];
-    int64_t off_next = tile_off[R.first];
-    const bool dkl = A.tri && R.K == R.L;
-    for (int t = 0; t < R.count; t++) {
-        const int I0 = I_next * BLK;
-        const int64_t toff = off_next;
-        const bool dij = A.tri && I_next == R.J;     // only a run's first tile can lie on the I == J diagonal
-        if (t + 1 < R.count) { I_next = tile_I[R.first + t + 1]; off_next = tile_off[R.first + t + 1]; }
-        d2_t *slot = lds + (t & 1) * 64;
-        if (dkl) {
-            if (dij) jk_digest_half<NT, true, true, VAR>(A, lane, i, k, w, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk, slot);
-            else jk_digest_half<NT, false, true, VAR>(A, lane, i, k, w, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk, slot);
-        } else {
-            if (dij) jk_digest_half<NT, true, false, VAR>(A, lane, i, k, w, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk, slot);
-            else jk_digest_half<NT, false, false, VAR>(A, lane, i, k, w, I0, J0, K0, L0, ld, bk, toff, dKL, dJK, kjl, jkl, kjk, slot);
-        }
-    }
-    // per-run outputs: J_KL partial over this wave's j rows; K_JK and K_JL rows j = 4 w + (0..3) (lanes i < 4 after the reduce-scatter)
-    {
-        const double r = reduce8(jkl, lane, 32, 16, 8); // lane holds l = i
-        atomicAdd(&A.Jacc[(size_t)(K0 + k) * ld + L0 + i], r);
-    }
-    double pad[8];
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) { pad[jj] = kjk[jj]; pad[jj + 4] = 0.0; }
-    const double rk = reduce8(pad, lane, 32, 16, 8);    // lanes i < 4 hold j = 4 w + i
-    double s8[8];
-#pragma unroll
-    for (int l = 0; l < 8; l++) {
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) { pad[jj] = kjl[jj][l]; pad[jj + 4] = 0.0; }
-        s8[l] = reduce8(pad, lane, 32, 16, 8);
-    }
-    const double r2 = reduce8(s8, lane, 4, 2, 1);       // lane holds l = k, summed over the k-lanes
-    if (i < 4) {
-        atomicAdd(&A.Kacc[(size_t)(J0 + 4 * w + i) * ld + K0 + k], rk);
-        atomicAdd(&A.Kacc[(size_t)(J0 + 4 * w + i) * ld + L0 + k], r2);
-    }
-}
-
-template <bool NT, int VAR>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void jk_tiles_split_kernel(JkArgs A)
-{
-    __shared__ d2_t lds[128];
-    const MI_CONST_AS int *wave_seg = as_const(A.wave_seg);
-    const int seg_end = wave_seg[blockIdx.x + 1];
-    for (int seg = wave_seg[blockIdx.x]; seg < seg_end; seg++) {
-        if (NT && seg < A.n_cached) jk_segment_split<false, VAR>(A, seg, lds);
-        else jk_segment_split<NT, VAR>(A, seg, lds);
-    }
-}
-
 template <bool WITH_J, bool WITH_K, bool NT>
 __global__ __launch_bounds__(128) void jk_tiles_pair_kernel(JkArgs A)
 {
@@ -3492,15 +3327,6 @@ static int launch_jk(mi_ctx *c, bool wj, bool wk, hipStream_t st)
     if (pipe && wk) {
         if (wj) { if (nt) hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, true, false>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_pipe_kernel<true, false, false>), g, b, 0, st, A); }
         else hipLaunchKernelGGL((jk_tiles_pipe_kernel<false, true, false>), g, b, 0, st, A);
-    }
-    else if (wj && wk && c->opt_jk_split) {
-        const dim3 b2(128);
-        switch ((c->opt_jk_split - 1) & 3) {   // experiment: bit 0 scheduling barriers per row, bit 1 LDS merge of the partial blocks
-        case 0: if (nt) hipLaunchKernelGGL((jk_tiles_split_kernel<true, 0>), g, b2, 0, st, A); else hipLaunchKernelGGL((jk_tiles_split_kernel<false, 0>), g, b2, 0, st, A); break;
-        case 1: if (nt) hipLaunchKernelGGL((jk_tiles_split_kernel<true, 1>), g, b2, 0, st, A); else hipLaunchKernelGGL((jk_tiles_split_kernel<false, 1>), g, b2, 0, st, A); break;
-        case 2: if (nt) hipLaunchKernelGGL((jk_tiles_split_kernel<true, 2>), g, b2, 0, st, A); else hipLaunchKernelGGL((jk_tiles_split_kernel<false, 2>), g, b2, 0, st, A); break;
-        default: if (nt) hipLaunchKernelGGL((jk_tiles_split_kernel<true, 3>), g, b2, 0, st, A); else hipLaunchKernelGGL((jk_tiles_split_kernel<false, 3>), g, b2, 0, st, A); break;
-        }
     }
     else if (wj && wk && c->opt_jk_kjlt) { if (nt) hipLaunchKernelGGL((jk_tiles_kjlt_kernel<true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kjlt_kernel<false>), g, b, 0, st, A); }
     else if (wj && wk) { if (nt) hipLaunchKernelGGL((jk_tiles_kernel<true, true, true>), g, b, 0, st, A); else hipLaunchKernelGGL((jk_tiles_kernel<true, true, false>), g, b, 0, st, A); }
