@@ -325,6 +325,8 @@ struct mi_ctx {
     int opt_tri_tiles = 1;   // block-diagonal tiles store triangular rows (0: the full-row layout of round 1); next mi_eri_prepare
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
+    int opt_grad_ablate = 0;
+    int opt_grad_live = 1;   // gradient: wave-per-quartet launches walk the compacted list of density-screened quartets
     int opt_jk_kjlt = 0;     // J+K: K_JL reduced per tile instead of run-wide accumulators (two waves per SIMD), experiment
     int opt_jk_dpp = 1;      // per-tile reduce-scatters of the J/K kernel through DPP moves (0: ds_bpermute, the round-1/2 path)
     int opt_jk_pipe = -1;    // software-pipelined half-tile kernel for the K-carrying builds (-1: when the tensor is cache-resident)
@@ -579,6 +581,8 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else if (k == "jk_dpp") c->opt_jk_dpp = (int)value;
     else if (k == "jk_kjlt") c->opt_jk_kjlt = (int)value;
+    else if (k == "grad_ablate") c->opt_grad_ablate = (int)value;
+    else if (k == "grad_live") c->opt_grad_live = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
     else if (k == "jk_pair") c->opt_jk_pair = (int)value;
     else if (k == "sp2_persist") c->opt_sp2_persist = (int)value;
@@ -883,6 +887,73 @@ __global__ __launch_bounds__(256) void fill_tasks_kernel(const int64_t *prefix, 
     int ib, ik;
     find_task(prefix, nbra, t, ib, ik);
     out[t] = TaskIdx{ib, ik};
+}
+
+// Gradient, density-weighted screening: the (bra, ket) list of the LIVE quartets of a class pair, in task order (round 3).  The
+// bound is symmetric in the roles of the four shells, so one list serves the three permutations x three launches of the class:
+// before, every launch started a wave per Schwarz-surviving quartet and the dead ones (q_ab q_cd max|G| < grad_dtol) left after
+// decoding their task and reading two pair records, two Schwarz factors and six density maxima.
+struct LiveArgs {
+    const PairRec *bra, *ket;
+    const int64_t *prefix;
+    int nbra;
+    int64_t ntask;
+    const double *q_bra, *q_ket, *dmax;
+    int nbas_d;
+    double hyb, dtol;
+};
+__device__ inline bool task_is_live(const LiveArgs &A, int64_t t, int &ib, int &ik)
+{
+    find_task(A.prefix, A.nbra, t, ib, ik);
+    const int a = A.bra[ib].sh_i, b = A.bra[ib].sh_j, c = A.ket[ik].sh_i, d = A.ket[ik].sh_j;
+    return !(A.q_bra[ib] * A.q_ket[ik] * quartet_density_bound(A.dmax, A.nbas_d, a, b, c, d, A.hyb) < A.dtol);
+}
+__global__ __launch_bounds__(256) void live_count_kernel(LiveArgs A, int *block_counts)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int ib, ik;
+    const bool live = t < A.ntask && task_is_live(A, t, ib, ik);
+    const int n = __syncthreads_count(live);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = n;
+}
+// exclusive prefix sum of `n` block counts by ONE workgroup (n <= a few 1e5); offsets[n] = total
+__global__ __launch_bounds__(1024) void live_scan_kernel(const int *counts, int n, int64_t *offsets)
+{
+    __shared__ int64_t part[1024];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int idx = base + threadIdx.x;
+        const int64_t v = idx < n ? counts[idx] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan
+            const int64_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (idx < n) offsets[idx] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n] = carry;
+}
+__global__ __launch_bounds__(256) void live_fill_kernel(LiveArgs A, const int64_t *offsets, TaskIdx *out)
+{
+    __shared__ int wave_base[4];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int ib = 0, ik = 0;
+    const bool live = t < A.ntask && task_is_live(A, t, ib, ik);
+    const unsigned long long m = __ballot(live);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_base[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wave_base[w];
+    if (live) out[offsets[blockIdx.x] + base + __popcll(m & ((1ull << lane) - 1ull))] = TaskIdx{ib, ik};
 }
 
 // Does any AO quadruple of the shell quartet land in a tile that is resident on this rank?  (<= 16 block
@@ -5163,6 +5234,7 @@ struct GradXfArgs {
     int64_t zs_i, zs_j;
     const int *ket_atom;
     double w0;
+    int ablate;   // TEMPORARY timing experiment: phases skipped (wrong results)
 };
 #define GRAD_COPIES 4096
 
@@ -5201,13 +5273,13 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
     const int ld = A.ld;
     if (live) {
         const double *gp = A.work_p + (size_t)tl * A.ncomp_p;
-        for (int c = lane; c < A.ne_p * nf; c += GSZ) E0p[c] = gp[c];
+        if (!(A.ablate & 1)) for (int c = lane; c < A.ne_p * nf; c += GSZ) E0p[c] = gp[c];
         if (has_m) {
             m_off_m = A.dminus[ib].m_off;
             const double *gm = A.work_m + (size_t)tl * A.ncomp_m;
-            for (int c = lane; c < A.ne_m * nf; c += GSZ) E0m[c] = gm[c];
+            if (!(A.ablate & 1)) for (int c = lane; c < A.ne_m * nf; c += GSZ) E0m[c] = gm[c];
         }
-        for (int o = lane; o < nsab * A.nscd; o += GSZ) {
+        if (!(A.ablate & 2)) for (int o = lane; o < nsab * A.nscd; o += GSZ) {
             int r = o / A.nscd, c = o - r * A.nscd;
             int sa = r / A.ns2, sb = r - sa * A.ns2, sc = c / A.nsd, sd = c - sc * A.nsd;
             int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
@@ -5221,7 +5293,7 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
     __syncthreads();
     // the three small matrix products run on the FP64 MFMA pipe when the whole wave works on one quartet and the
     // 16x16x4 padding does not eat the gain (wave-uniform decisions); otherwise plain per-lane dot products
-    if (live) {
+    if (live && !(A.ablate & 4)) {
         const double *Mcd = A.Mbuf + cd.m_off;
         if (MFMA && GSZ >= 64 && mfma_worthwhile(nsab, nf, A.nscd)) {
             int tile = 0;
@@ -5246,7 +5318,7 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
     }
     __syncthreads();
     double acc[3] = {0.0, 0.0, 0.0};
-    if (live) {
+    if (live && !(A.ablate & 8)) {
         for (int var = 0; var < (has_m ? 2 : 1); var++) {
             const double *Mx = A.Mbuf + (var == 0 ? dp.m_off : m_off_m);
             const double *E0 = var == 0 ? E0p : E0m;
@@ -5263,6 +5335,7 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
                             int r = m0 + (wl >> 4) + 4 * q, e = n0 + (wl & 15);
                             if (r < nsab && e < ne) {
                                 size_t o = (size_t)r * ne + e;
+                                if (A.ablate & 16) { acc[0] += z[q]; continue; }
                                 acc[0] += Mx[o] * z[q]; acc[1] += Mx[xs + o] * z[q]; acc[2] += Mx[2 * xs + o] * z[q];
                             }
                         }
@@ -5272,6 +5345,7 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
                     int r = o / ne, e = o - r * ne;
                     double z = 0.0;
                     for (int f = 0; f < nf; f++) z += E0[e * nf + f] * Y[r * nf + f];
+                    if (A.ablate & 16) { acc[0] += z; continue; }
                     acc[0] += Mx[o] * z; acc[1] += Mx[xs + o] * z; acc[2] += Mx[2 * xs + o] * z;
                 }
             }
@@ -5284,7 +5358,7 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
     for (int x = 0; x < 3; x++) {
         double v = acc[x];
         for (int o = (GSZ < 64 ? GSZ : 64) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (live && (lane & ((GSZ < 64 ? GSZ : 64) - 1)) == 0) { // one partial sum per wave (per 16-lane group for GSZ = 16)
+        if (live && !(A.ablate & 32) && (lane & ((GSZ < 64 ? GSZ : 64) - 1)) == 0) { // one partial sum per wave (per 16-lane group for GSZ = 16)
             double *gc = A.grad + (size_t)((blockIdx.x * QPW + grp) & (GRAD_COPIES - 1)) * A.natm3;
             atomicAdd(&gc[A.shell_atom[dp.sh_i] * 3 + x], w * v);
             // the skipped permutation (derivative on the first shell of the bra pair P) by invariance; density fitting:
@@ -5325,6 +5399,7 @@ struct TpqGradArgs {
     const double *q_bra, *q_ket, *dmax;
     int nbas_d;
     double dtol;
+    const TaskIdx *tasks;     // non-null: the compacted list of live quartets (already screened: dmax is null then)
 };
 
 template <int L1, int L2, int LC, int LD>
@@ -5348,7 +5423,7 @@ __global__ __launch_bounds__(TPQ_BLOCK) void eri_tpq_grad_kernel(TpqGradArgs A)
     const int64_t tl = (int64_t)blockIdx.x * TPQ_BLOCK + threadIdx.x;
     bool live = tl < A.ntask;
     int ib = 0, ik = 0;
-    if (live) find_task(A.prefix, A.nbra, A.t0 + tl, ib, ik);
+    if (live) get_task(A.tasks, A.prefix, A.nbra, A.t0 + tl, ib, ik);
     const bool same_pair = A.same_class && ib == ik;
     if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
     const PairRec dp = A.dplus[ib], cd = A.ket[ik];
@@ -5604,10 +5679,12 @@ static int launch_eri_tpq_grad_t(const TpqGradArgs &Q, hipStream_t st)
 }
 
 // returns 1 if the class (l1 = differentiated shell, l2 = partner | lc >= ld) has a thread-per-quartet kernel, 0 otherwise
-static int launch_eri_tpq_grad(int l1, int l2, int lc, int ld, const TpqGradArgs &Q, hipStream_t st)
+// (dry = true: only answers the question)
+static int launch_eri_tpq_grad(int l1, int l2, int lc, int ld, const TpqGradArgs &Q, hipStream_t st, bool dry = false)
 {
+    if (l1 > 3 || l2 > 3 || lc > 3 || ld > 3) return 0;
     const int key = ((l1 * 4 + l2) * 4 + lc) * 4 + ld;
-#define TPQG_CASE(a, b, c_, d) case (((a) * 4 + (b)) * 4 + (c_)) * 4 + (d): return launch_eri_tpq_grad_t<a, b, c_, d>(Q, st)
+#define TPQG_CASE(a, b, c_, d) case (((a) * 4 + (b)) * 4 + (c_)) * 4 + (d): return dry ? 1 : launch_eri_tpq_grad_t<a, b, c_, d>(Q, st)
     switch (key) {
         // other pair (ss)
         TPQG_CASE(0, 0, 0, 0); TPQG_CASE(1, 0, 0, 0); TPQG_CASE(0, 1, 0, 0); TPQG_CASE(1, 1, 0, 0); TPQG_CASE(2, 0, 0, 0);
@@ -5629,6 +5706,12 @@ static int launch_eri_tpq_grad(int l1, int l2, int lc, int ld, const TpqGradArgs
     default: return 0;
     }
 #undef TPQG_CASE
+}
+
+static bool tpq_grad_has_class(int l1, int l2, int lc, int ld)
+{
+    TpqGradArgs none{};
+    return launch_eri_tpq_grad(l1, l2, lc, ld, none, nullptr, true) == 1;
 }
 
 // max |D| over the AO block of every shell pair (density-weighted screening of the derivative quartets)
@@ -5729,8 +5812,10 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
     HIPCHK(hipMalloc(&d_comp_m, sizeof(uint32_t) * 16384));
     int64_t *d_prefix = nullptr;
     size_t prefix_cap = 0;
-    TaskIdx *d_tasks = nullptr;
-    size_t tasks_cap = 0;
+    TaskIdx *d_tasks = nullptr, *d_live_tasks = nullptr;
+    size_t tasks_cap = 0, live_tasks_cap = 0, live_cap = 0;
+    int *d_live_counts = nullptr;
+    int64_t *d_live_off = nullptr;
     const double tol = c->tol;
     int64_t batch_counter = 0;
     for (int bc = 0; bc < NPC; bc++)
@@ -5757,6 +5842,37 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 tasks_dev = d_tasks;
             }
             HIPCHK(hipStreamSynchronize(st));
+            // wave-per-quartet launches of this class walk the list of LIVE quartets (density-weighted screening done once, see
+            // live_fill_kernel); built on first need -- classes wholly on the thread-per-quartet path never ask for it
+            int64_t nlive = -1;
+            auto ensure_live = [&]() -> int {
+                if (nlive >= 0 || !d_dmax || !c->opt_grad_live || ntask < 4096) return 0;
+                const int nblk = (int)((ntask + 255) / 256);
+                if ((size_t)nblk + 1 > live_cap) {
+                    if (d_live_counts) hipFree(d_live_counts);
+                    if (d_live_off) hipFree(d_live_off);
+                    live_cap = (size_t)nblk + 1 + (size_t)nblk / 4;
+                    HIPCHK(hipMalloc(&d_live_counts, sizeof(int) * live_cap));
+                    HIPCHK(hipMalloc(&d_live_off, sizeof(int64_t) * live_cap));
+                }
+                if ((size_t)ntask > live_tasks_cap) {
+                    if (d_live_tasks) hipFree(d_live_tasks);
+                    live_tasks_cap = (size_t)ntask + (size_t)ntask / 4;
+                    HIPCHK(hipMalloc(&d_live_tasks, sizeof(TaskIdx) * live_tasks_cap));
+                }
+                LiveArgs L{B.d_recs, Kc.d_recs, d_prefix, (int)B.recs.size(), ntask, B.d_q, Kc.d_q, d_dmax, c->nbas, hyb, c->opt_grad_dtol};
+                hipLaunchKernelGGL(live_count_kernel, dim3(nblk), dim3(256), 0, st, L, d_live_counts);
+                hipLaunchKernelGGL(live_scan_kernel, dim3(1), dim3(1024), 0, st, d_live_counts, nblk, d_live_off);
+                hipLaunchKernelGGL(live_fill_kernel, dim3(nblk), dim3(256), 0, st, L, d_live_off, d_live_tasks);
+                HIPCHK(hipGetLastError());
+                int64_t n = 0;
+                HIPCHK(hipMemcpyAsync(&n, d_live_off + nblk, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                nlive = n;
+                if (getenv("MI355_DEBUG"))
+                    fprintf(stderr, "[mi355] grad class pair (%d%d|%d%d): %ld of %ld quartets live\n", B.la, B.lb, Kc.la, Kc.lb, (long)nlive, (long)ntask);
+                return 0;
+            };
             // perm 0 (derivative on P.sh_i, the costliest: highest l) is skipped: sum of the four forces = 0
             for (int perm = 1; perm < 4; perm++) {
                 const bool swap = perm >= 2;
@@ -5769,15 +5885,20 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                     TpqGradArgs Q{};
                     Q.dplus = Dc.d_g_recs[orient][0]; Q.dminus = l1 >= 1 ? Dc.d_g_recs[orient][1] : nullptr; Q.ket = Oc.d_recs;
                     Q.prim = c->d_prim; Q.prefix = d_prefix; Q.nbra = (int)B.recs.size();
-                    // this rank's contiguous share of the task list
-                    const int64_t lo_t = ntask * rank / nranks, hi_t = ntask * (rank + 1) / nranks;
+                    // this rank's contiguous share of the task list (the compacted live list when the class has a kernel)
+                    const bool has_tpq = tpq_grad_has_class(l1, l2, lc, ldd);
+                    if (has_tpq && ensure_live()) return -1;
+                    const bool live_q = has_tpq && nlive >= 0;
+                    const int64_t nt_q = live_q ? nlive : ntask;
+                    const int64_t lo_t = nt_q * rank / nranks, hi_t = nt_q * (rank + 1) / nranks;
                     Q.t0 = lo_t; Q.ntask = hi_t - lo_t;
+                    Q.tasks = live_q ? d_live_tasks : nullptr;
                     Q.swap = swap ? 1 : 0; Q.same_class = (bc == kc);
                     Q.c2s = c->d_c2s;
                     for (int q = 0; q <= LMAX + 1; q++) Q.c2s_off[q] = c->c2s_off[q];
                     Q.rys = c->rys; Q.shell_xyz = c->d_shell_xyz; Q.D = c->d_Dpad; Q.Dm = d_Mpad; Q.ld = c->ldp; Q.hyb = hyb;
                     Q.shell_atom = d_shell_atom; Q.grad = d_gcopies; Q.natm3 = natm3; Q.inv_from_second = swap ? 0 : 1;
-                    Q.q_bra = Dc.d_q; Q.q_ket = Oc.d_q; Q.dmax = d_dmax; Q.nbas_d = c->nbas; Q.dtol = c->opt_grad_dtol;
+                    Q.q_bra = Dc.d_q; Q.q_ket = Oc.d_q; Q.dmax = live_q ? nullptr : d_dmax; Q.nbas_d = c->nbas; Q.dtol = c->opt_grad_dtol;
                     const bool dbg1 = getenv("MI355_DEBUG") != nullptr;
                     auto tq0 = std::chrono::steady_clock::now();
                     if (dbg1) hipStreamSynchronize(st);
@@ -5792,6 +5913,12 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                         continue;
                     }
                 }
+                if (ensure_live()) return -1;
+                const bool use_live = nlive >= 0;
+                if (use_live && nlive == 0) continue;
+                const int64_t ntask_w = use_live ? nlive : ntask;            // tasks the wave-per-quartet launches walk
+                const TaskIdx *tasks_w = use_live ? d_live_tasks : tasks_dev;
+                const double *dmax_w = use_live ? nullptr : d_dmax;          // the live list is already screened
                 EriArgs Ep{}, Em{};
                 setup_eri_dims(Ep, l1 + 1, l2, lc, ldd);
                 const bool has_m = l1 >= 1;
@@ -5812,14 +5939,14 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                     Em.bra = Dc.d_g_recs[orient][1]; Em.ket = Oc.d_recs; Em.prim = c->d_prim; Em.prefix = d_prefix; Em.nbra = Ep.nbra;
                     Em.comp = d_comp_m; Em.work = d_wm; Em.rys = c->rys; Em.diag = 0; Em.swap = Ep.swap;
                 }
-                Ep.tasks = Em.tasks = tasks_dev;
+                Ep.tasks = Em.tasks = tasks_w;
                 Ep.prim_lds = Em.prim_lds = (c->opt_prim_lds && B.max_np + Kc.max_np <= 160) ? B.max_np + Kc.max_np : 0;
                 Ep.h_shared_np = B.mean_np; Ep.h_vary_mean = Kc.mean_np; Ep.h_vary_max4 = Kc.max4_np;
                 Em.h_shared_np = B.mean_np; Em.h_vary_mean = Kc.mean_np; Em.h_vary_max4 = Kc.max4_np;
-                Ep.q_bra = Dc.d_q; Ep.q_ket = Oc.d_q; Ep.dmax = d_dmax; Ep.nbas_d = c->nbas; Ep.dtol = c->opt_grad_dtol; Ep.hyb = hyb;
-                if (has_m) { Em.q_bra = Ep.q_bra; Em.q_ket = Ep.q_ket; Em.dmax = d_dmax; Em.nbas_d = c->nbas; Em.dtol = Ep.dtol; Em.hyb = hyb; }
+                Ep.q_bra = Dc.d_q; Ep.q_ket = Oc.d_q; Ep.dmax = dmax_w; Ep.nbas_d = c->nbas; Ep.dtol = c->opt_grad_dtol; Ep.hyb = hyb;
+                if (has_m) { Em.q_bra = Ep.q_bra; Em.q_ket = Ep.q_ket; Em.dmax = dmax_w; Em.nbas_d = c->nbas; Em.dtol = Ep.dtol; Em.hyb = hyb; }
                 GradXfArgs X{};
-                X.q_bra = Ep.q_bra; X.q_ket = Ep.q_ket; X.dmax = d_dmax; X.nbas_d = c->nbas; X.dtol = Ep.dtol;
+                X.q_bra = Ep.q_bra; X.q_ket = Ep.q_ket; X.dmax = dmax_w; X.nbas_d = c->nbas; X.dtol = Ep.dtol;
                 X.dplus = Dc.d_g_recs[orient][0]; X.dminus = has_m ? Dc.d_g_recs[orient][1] : nullptr; X.ket = Oc.d_recs;
                 X.Mbuf = c->d_M; X.prefix = d_prefix; X.nbra = Ep.nbra; X.swap = Ep.swap; X.same_class = (bc == kc);
                 X.ne_p = ne_of(l1 + 1, l2); X.ne_m = has_m ? ne_of(l1 - 1, l2) : 0; X.nf = Oc.ne;
@@ -5827,17 +5954,18 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 X.work_p = d_wp; X.work_m = d_wm; X.ncomp_p = Ep.ncomp; X.ncomp_m = has_m ? Em.ncomp : 0;
                 X.D = c->d_Dpad; X.Dm = d_Mpad; X.ld = c->ldp; X.hyb = hyb; X.shell_atom = d_shell_atom; X.grad = d_gcopies; X.natm3 = natm3;
                 X.inv_from_second = swap ? 0 : 1;
-                X.tasks = tasks_dev;
+                X.tasks = tasks_w;
+                X.ablate = c->opt_grad_ablate;
                 size_t shm = sizeof(double) * ((size_t)X.ne_p * X.nf + (size_t)X.ne_m * X.nf + (size_t)X.ns1 * X.ns2 * (X.nf + X.nscd));
                 if (shm > 160 * 1024) return fail("gradient contraction needs %zu bytes of LDS", shm);
                 const bool dbg = getenv("MI355_DEBUG") != nullptr;
                 auto tc0 = std::chrono::steady_clock::now();
                 if (dbg) hipStreamSynchronize(st);
                 int64_t per = std::min<int64_t>((int64_t)(WORK_DOUBLES / Ep.ncomp), (int64_t)1 << 23);
-                if (nranks > 1) per = std::min<int64_t>(per, std::max<int64_t>(1024, ntask / (8 * nranks)));
-                for (int64_t t0 = 0; t0 < ntask; t0 += per) {
+                if (nranks > 1) per = std::min<int64_t>(per, std::max<int64_t>(1024, ntask_w / (8 * nranks)));
+                for (int64_t t0 = 0; t0 < ntask_w; t0 += per) {
                     if ((int)((batch_counter++) % nranks) != rank) continue; // batches dealt round-robin to ranks
-                    int nb = (int)std::min<int64_t>(per, ntask - t0);
+                    int nb = (int)std::min<int64_t>(per, ntask_w - t0);
                     Ep.t0 = t0; Ep.ntask = nb;
                     if (launch_eri(c, Ep, nb, st)) return -1;
                     if (has_m) { Em.t0 = t0; Em.ntask = nb; if (launch_eri(c, Em, nb, st)) return -1; }
@@ -5876,6 +6004,9 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count());
     if (d_prefix) hipFree(d_prefix);
     if (d_tasks) hipFree(d_tasks);
+    if (d_live_tasks) hipFree(d_live_tasks);
+    if (d_live_counts) hipFree(d_live_counts);
+    if (d_live_off) hipFree(d_live_off);
     hipFree(d_wp); hipFree(d_wm); hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_shell_atom);
     if (d_dmax) hipFree(d_dmax);
     if (d_Mpad) hipFree(d_Mpad);

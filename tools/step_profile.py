@@ -17,7 +17,7 @@ for step in range(3):
     m2 = mol.set_geom_(R + 0.01 * rng.standard_normal(R.shape), unit="Bohr", inplace=False)
     t0 = time.time(); e, g = gs(m2); torch.cuda.synchronize(); dt = time.time() - t0
     tm = dict(mf.timing)
-    print(f"step {step}: {dt:.2f} s  cycles {mf.cycles}  SCF total {tm.get('total_seconds', 0):.2f} (setup {tm.get('setup_seconds', 0):.2f}, eri {tm.get('eri_seconds', 0):.2f}, loop {tm.get('loop_seconds', 0):.2f})  gradient+rest {dt - tm.get('total_seconds', 0):.2f}", flush=True)
+    print(f"step {step}: {dt:.2f} s  cycles {mf.cycles}  SCF total {tm.get('total_seconds', 0):.2f} (setup {tm.get('setup_seconds', 0):.2f}, eri {tm.get('eri_seconds', 0):.2f}, loop {tm.get('loop_seconds', 0):.2f})  gradient+rest {dt - tm.get('total_seconds', 0):.2f}  gradient parts {({k: round(v, 3) for k, v in getattr(gs.g, 'timing', {}).items()})}", flush=True)
 if "--cprofile" in sys.argv:
     import cProfile, pstats
     m2 = mol.set_geom_(R + 0.01 * rng.standard_normal(R.shape), unit="Bohr", inplace=False)
