@@ -325,7 +325,6 @@ struct mi_ctx {
     int opt_tri_tiles = 1;   // block-diagonal tiles store triangular rows (0: the full-row layout of round 1); next mi_eri_prepare
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
-    int opt_grad_ablate = 0;
     int opt_grad_live = 1;   // gradient: wave-per-quartet launches walk the compacted list of density-screened quartets
     int opt_jk_kjlt = 0;     // J+K: K_JL reduced per tile instead of run-wide accumulators (two waves per SIMD), experiment
     int opt_jk_dpp = 1;      // per-tile reduce-scatters of the J/K kernel through DPP moves (0: ds_bpermute, the round-1/2 path)
@@ -581,7 +580,6 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_pipe") c->opt_jk_pipe = (int)value;
     else if (k == "jk_dpp") c->opt_jk_dpp = (int)value;
     else if (k == "jk_kjlt") c->opt_jk_kjlt = (int)value;
-    else if (k == "grad_ablate") c->opt_grad_ablate = (int)value;
     else if (k == "grad_live") c->opt_grad_live = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
     else if (k == "jk_pair") c->opt_jk_pair = (int)value;
@@ -5234,7 +5232,6 @@ struct GradXfArgs {
     int64_t zs_i, zs_j;
     const int *ket_atom;
     double w0;
-    int ablate;   // TEMPORARY timing experiment: phases skipped (wrong results)
 };
 #define GRAD_COPIES 4096
 
@@ -5271,15 +5268,24 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
     int m_off_m = 0;
     const double *D = A.D;
     const int ld = A.ld;
+    // the first E0PRE x GSZ elements of the plus block travel through registers: their loads are issued here and land in LDS only
+    // after the Y product, so the HBM round trip of the hand-over block overlaps the G gather and the first matrix product
+    constexpr int E0PRE = (GSZ >= 64 && MFMA) ? 8 : 0;
+    double pre[E0PRE > 0 ? E0PRE : 1];
+    const int n_e0p = A.ne_p * nf;
     if (live) {
         const double *gp = A.work_p + (size_t)tl * A.ncomp_p;
-        if (!(A.ablate & 1)) for (int c = lane; c < A.ne_p * nf; c += GSZ) E0p[c] = gp[c];
+        if (E0PRE > 0) {
+#pragma unroll
+            for (int q = 0; q < E0PRE; q++) { const int c = lane + q * GSZ; pre[q] = c < n_e0p ? gp[c] : 0.0; }
+        }
+        for (int c = lane + E0PRE * GSZ; c < n_e0p; c += GSZ) E0p[c] = gp[c];
         if (has_m) {
             m_off_m = A.dminus[ib].m_off;
             const double *gm = A.work_m + (size_t)tl * A.ncomp_m;
-            if (!(A.ablate & 1)) for (int c = lane; c < A.ne_m * nf; c += GSZ) E0m[c] = gm[c];
+            for (int c = lane; c < A.ne_m * nf; c += GSZ) E0m[c] = gm[c];
         }
-        if (!(A.ablate & 2)) for (int o = lane; o < nsab * A.nscd; o += GSZ) {
+        for (int o = lane; o < nsab * A.nscd; o += GSZ) {
             int r = o / A.nscd, c = o - r * A.nscd;
             int sa = r / A.ns2, sb = r - sa * A.ns2, sc = c / A.nsd, sd = c - sc * A.nsd;
             int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
@@ -5293,7 +5299,7 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
     __syncthreads();
     // the three small matrix products run on the FP64 MFMA pipe when the whole wave works on one quartet and the
     // 16x16x4 padding does not eat the gain (wave-uniform decisions); otherwise plain per-lane dot products
-    if (live && !(A.ablate & 4)) {
+    if (live) {
         const double *Mcd = A.Mbuf + cd.m_off;
         if (MFMA && GSZ >= 64 && mfma_worthwhile(nsab, nf, A.nscd)) {
             int tile = 0;
@@ -5316,9 +5322,13 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
             }
         }
     }
+    if (E0PRE > 0 && live) {
+#pragma unroll
+        for (int q = 0; q < E0PRE; q++) { const int c = lane + q * GSZ; if (c < n_e0p) E0p[c] = pre[q]; }
+    }
     __syncthreads();
     double acc[3] = {0.0, 0.0, 0.0};
-    if (live && !(A.ablate & 8)) {
+    if (live) {
         for (int var = 0; var < (has_m ? 2 : 1); var++) {
             const double *Mx = A.Mbuf + (var == 0 ? dp.m_off : m_off_m);
             const double *E0 = var == 0 ? E0p : E0m;
@@ -5335,7 +5345,6 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
                             int r = m0 + (wl >> 4) + 4 * q, e = n0 + (wl & 15);
                             if (r < nsab && e < ne) {
                                 size_t o = (size_t)r * ne + e;
-                                if (A.ablate & 16) { acc[0] += z[q]; continue; }
                                 acc[0] += Mx[o] * z[q]; acc[1] += Mx[xs + o] * z[q]; acc[2] += Mx[2 * xs + o] * z[q];
                             }
                         }
@@ -5345,7 +5354,6 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
                     int r = o / ne, e = o - r * ne;
                     double z = 0.0;
                     for (int f = 0; f < nf; f++) z += E0[e * nf + f] * Y[r * nf + f];
-                    if (A.ablate & 16) { acc[0] += z; continue; }
                     acc[0] += Mx[o] * z; acc[1] += Mx[xs + o] * z; acc[2] += Mx[2 * xs + o] * z;
                 }
             }
@@ -5358,7 +5366,7 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
     for (int x = 0; x < 3; x++) {
         double v = acc[x];
         for (int o = (GSZ < 64 ? GSZ : 64) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (live && !(A.ablate & 32) && (lane & ((GSZ < 64 ? GSZ : 64) - 1)) == 0) { // one partial sum per wave (per 16-lane group for GSZ = 16)
+        if (live && (lane & ((GSZ < 64 ? GSZ : 64) - 1)) == 0) { // one partial sum per wave (per 16-lane group for GSZ = 16)
             double *gc = A.grad + (size_t)((blockIdx.x * QPW + grp) & (GRAD_COPIES - 1)) * A.natm3;
             atomicAdd(&gc[A.shell_atom[dp.sh_i] * 3 + x], w * v);
             // the skipped permutation (derivative on the first shell of the bra pair P) by invariance; density fitting:
@@ -5955,7 +5963,6 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 X.D = c->d_Dpad; X.Dm = d_Mpad; X.ld = c->ldp; X.hyb = hyb; X.shell_atom = d_shell_atom; X.grad = d_gcopies; X.natm3 = natm3;
                 X.inv_from_second = swap ? 0 : 1;
                 X.tasks = tasks_w;
-                X.ablate = c->opt_grad_ablate;
                 size_t shm = sizeof(double) * ((size_t)X.ne_p * X.nf + (size_t)X.ne_m * X.nf + (size_t)X.ns1 * X.ns2 * (X.nf + X.nscd));
                 if (shm > 160 * 1024) return fail("gradient contraction needs %zu bytes of LDS", shm);
                 const bool dbg = getenv("MI355_DEBUG") != nullptr;

@@ -1,2 +1,9 @@
 #!/bin/bash
-for o in "grad_dtol=1e-13" "grad_dtol=1e-11" "grad_dtol=1e-10" "grad_dtol=1e-9" "grad_dtol=1e-8"; do echo "$o"; ERI_OPTS="$o" python tools/eri_bench.py ibuprofen def2-TZVP --grad --quiet 2>&1 | grep grad_eri_s; done
+# A/B of two builds on the same box: tools/probes/libmi355scf_old.so (copy of the previous build) against the current one,
+# gradient of ibuprofen/def2-TZVP at the optimiser's screening threshold, alternating
+for rep in 1 2 3; do
+  for lib in tools/probes/libmi355scf_old.so ""; do
+    echo -n "${lib:-current} "
+    MI355SCF_LIB=$lib ERI_OPTS="grad_dtol=1e-10" python tools/eri_bench.py ibuprofen def2-TZVP --grad --quiet 2>&1 | grep grad_eri_s | tr '\n' ' '; echo
+  done
+done
