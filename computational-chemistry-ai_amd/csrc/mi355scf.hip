@@ -54,6 +54,7 @@ extern "C" const char *mi_last_error(void) { return g_err.c_str(); }
 
 // Host-side OpenMP is used only for the per-pair transformation matrices.  Idle workers must not spin
 // (libomp's default 200 ms block time starves the Python/torch threads between calls).
+static int g_rows_g32 = 1;   // (option grad_rows_g32) row gradient kernel: lane groups of 32 (two quartets per wave) up to 64 rows
 static int host_threads()
 {
     static int n = [] {
@@ -325,6 +326,8 @@ struct mi_ctx {
     int opt_tri_tiles = 1;   // block-diagonal tiles store triangular rows (0: the full-row layout of round 1); next mi_eri_prepare
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
+    int opt_grad_rows = 1;   // gradient: row kernel (eri_grad_rows_kernel) for the classes it covers
+    int opt_grad_rows_min = 20;  // ... when the two derivative blocks have at least this many rows
     int opt_grad_live = 1;   // gradient: wave-per-quartet launches walk the compacted list of density-screened quartets
     int opt_jk_kjlt = 0;     // J+K: K_JL reduced per tile instead of run-wide accumulators (two waves per SIMD), experiment
     int opt_jk_dpp = 1;      // per-tile reduce-scatters of the J/K kernel through DPP moves (0: ds_bpermute, the round-1/2 path)
@@ -581,6 +584,9 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_dpp") c->opt_jk_dpp = (int)value;
     else if (k == "jk_kjlt") c->opt_jk_kjlt = (int)value;
     else if (k == "grad_live") c->opt_grad_live = (int)value;
+    else if (k == "grad_rows") c->opt_grad_rows = (int)value;
+    else if (k == "grad_rows_min") c->opt_grad_rows_min = (int)value;
+    else if (k == "grad_rows_g32") g_rows_g32 = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
     else if (k == "jk_pair") c->opt_jk_pair = (int)value;
     else if (k == "sp2_persist") c->opt_sp2_persist = (int)value;
@@ -5378,6 +5384,276 @@ __global__ __launch_bounds__(GSZ > 64 ? GSZ : 64) void eri_grad_contract(GradXfA
 }
 
 // =================================================================================================
+// Derivative ERIs contracted with the two-particle density, MID / HIGH classes, "row" kernel (round 3).
+//
+// One wave per (live quartet, permutation), NOTHING handed over: lane e owns ROW e of the contracted [e0|f0] blocks of both
+// derivative variants (rows 0 .. ne_p-1: the (l1+1, l2) block, rows ne_p .. ne_p+ne_m-1: the (l1-1, l2) block; ROWS rows per
+// lane) and keeps its NF = ne(LC, LD) elements in REGISTERS; the other pair (LC, LD) is a template parameter, so the NF
+// products of a row per primitive quartet and root are straight-line code over 3 (LC+LD+1) table values the lane reads from
+// LDS once.  Roots, weights and the 2-D recurrence tables are computed by the wave exactly as in eri_rys_kernel (runtime l1,
+// l2); the (l1-1) rows share them -- same Gaussian product, the factor K-/K+ = 1 / (2 alpha) is applied per primitive pair.
+// The gradient is LINEAR in the block, so the row is contracted where it lives:
+//     Yk[c]  = sum_f E0[e][f] Mcd[c][f]                       (ket HRR + cart->sph, matrix in LDS)
+//     t_r    = sum_c Yk[c] G[r][c]                            (two-particle density block in LDS)
+//     g[x]  += Mx[x][r][e] t_r                                (row e of the derivative x HRR x c2s matrices, adjoint use)
+// and the wave sums g over its lanes.  Against the Rys -> hand-over -> eri_grad_contract pipeline this drops both hand-over
+// buffers (written and re-read once per variant), two of the three launches and their task decodes, all barriers outside the
+// Rys phases, and the Z product; every table value is read from LDS once per row instead of three per component.
+// =================================================================================================
+template <int LC, int LD>
+struct FTab {
+    static constexpr int NF = c_ne(LC, LD);
+    int fx[NF], fy[NF], fz[NF];
+    constexpr FTab() : fx{}, fy{}, fz{}
+    {
+        int n = 0;
+        for (int f = LC; f <= LC + LD; f++)
+            for (int a = f; a >= 0; a--)
+                for (int b = f - a; b >= 0; b--) { fx[n] = a; fy[n] = b; fz[n] = f - a - b; n++; }
+    }
+};
+
+struct GradRowsArgs {
+    const PairRec *dplus, *dminus, *ket;
+    const double *prim, *Mbuf;
+    const TaskIdx *tasks;
+    const int64_t *prefix;
+    int nbra;
+    int64_t t0, ntask;
+    int swap, same_class;
+    int nmax, nroots, tsz, PB;          // Rys set-up of the (l1+1, l2 | lc, ld) variant
+    int ne_p, ne_m, nsab, ns2;
+    const uint32_t *comp_p, *comp_m;    // component tables of the two variants (row bases: entry e * NF)
+    RysDev rys;
+    const double *D, *Dm;
+    int ld;
+    double hyb;
+    const int *shell_atom;
+    double *grad;
+    int natm3, inv_from_second;
+    const double *q_bra, *q_ket, *dmax;
+    int nbas_d;
+    double dtol;
+};
+
+// GSZ lanes per quartet (64 / GSZ quartets per wave): the Rys phases keep 2 n .. 3 n lanes per primitive quartet busy and the
+// rows of the low bra classes fill a fraction of a wave, so the small classes run two or four latency chains side by side.
+template <int LC, int LD, int ROWS, int GSZ>
+__global__ __launch_bounds__(64) void eri_grad_rows_kernel(GradRowsArgs A)
+{
+    constexpr int NF = c_ne(LC, LD), MMAX = LC + LD, M1 = MMAX + 1;
+    constexpr int NSC = 2 * LC + 1, NSD = 2 * LD + 1, NSCD = NSC * NSD;
+    constexpr int QPW = 64 / GSZ;
+    constexpr FTab<LC, LD> FT{};
+    extern __shared__ double lds_all[];
+    const int grp = QPW == 1 ? 0 : threadIdx.x / GSZ, lane = QPW == 1 ? threadIdx.x : threadIdx.x % GSZ;
+    const int64_t tl = (int64_t)blockIdx.x * QPW + grp;
+    bool live = tl < A.ntask;
+    int ib, ik;
+    get_task(A.tasks, A.prefix, A.nbra, A.t0 + (live ? tl : 0), ib, ik);
+    const bool same_pair = A.same_class && ib == ik;
+    if (A.swap) { int t_ = ib; ib = ik; ik = t_; }
+    const bool has_m = A.ne_m > 0;
+    const PairRec dp = A.dplus[ib], cd = A.ket[ik];
+    if (live && A.dmax && A.q_bra[ib] * A.q_ket[ik] * quartet_density_bound(A.dmax, A.nbas_d, dp.sh_i, dp.sh_j, cd.sh_i, cd.sh_j, A.hyb) < A.dtol)
+        live = false;
+    if (QPW == 1 && !live) return;
+    int m_prim = dp.prim_off, m_off_m = 0;
+    if (has_m) { const PairRec dm = A.dminus[ib]; m_prim = dm.prim_off; m_off_m = dm.m_off; }
+    const int n = A.nroots, tsz = A.tsz, PB = A.PB, nsab = A.nsab;
+    const size_t lds_per = (size_t)PB * n * 3 * tsz + (size_t)PB * 2 * n + PB + NSCD * NF + (size_t)nsab * NSCD;
+    double *T0 = lds_all + (size_t)grp * lds_per;          // [PB n][3][tsz]
+    double *rw = T0 + (size_t)PB * n * 3 * tsz;            // [PB][2 n]
+    double *rho = rw + (size_t)PB * 2 * n;                 // [PB]   K- / K+ of the bra primitive pair
+    double *McdL = rho + PB;                               // [NSCD][NF]
+    double *G = McdL + NSCD * NF;                          // [nsab][NSCD]
+    // ket matrix and two-particle density block (used after the Rys loop: its barriers order these writes)
+    if (live) {
+        const double *Mcd = A.Mbuf + cd.m_off;
+        for (int q = lane; q < NSCD * NF; q += GSZ) McdL[q] = Mcd[q];
+        const double *D = A.D;
+        const int ld = A.ld, ns2 = A.ns2;
+        for (int o = lane; o < nsab * NSCD; o += GSZ) {      // G[r][c], r = (sa, sb) of the differentiated pair, c = (sc, sd) of the other
+            const int r = o / NSCD, c = o - r * NSCD;
+            const int sa = r / ns2, sb = r - sa * ns2, sc = c / NSD, sd = c - sc * NSD;
+            const int i = dp.ao_i + sa, j = dp.ao_j + sb, k = cd.ao_i + sc, l = cd.ao_j + sd;
+            double ex = D[(size_t)i * ld + k] * D[(size_t)j * ld + l] + D[(size_t)i * ld + l] * D[(size_t)j * ld + k];
+            if (A.Dm) // sum_s Ds x Ds = (D x D + M x M) / 2
+                ex += A.Dm[(size_t)i * ld + k] * A.Dm[(size_t)j * ld + l] + A.Dm[(size_t)i * ld + l] * A.Dm[(size_t)j * ld + k];
+            G[o] = D[(size_t)i * ld + j] * D[(size_t)k * ld + l] - 0.25 * A.hyb * ex;
+        }
+    }
+    const int ne = A.ne_p + A.ne_m;
+    int bx[ROWS], by[ROWS], bz[ROWS];
+    bool valid[ROWS], minus[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; rr++) {
+        const int e = lane + GSZ * rr;
+        valid[rr] = live && e < ne;
+        minus[rr] = e >= A.ne_p;
+        uint32_t w = 0;
+        if (valid[rr]) w = minus[rr] ? A.comp_m[(size_t)(e - A.ne_p) * NF] : A.comp_p[(size_t)e * NF];
+        bx[rr] = (int)(w & 1023u) - LC; by[rr] = (int)((w >> 10) & 1023u); bz[rr] = (int)((w >> 20) & 1023u);
+    }
+    double acc[ROWS][NF];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; rr++)
+#pragma unroll
+        for (int f = 0; f < NF; f++) acc[rr][f] = 0.0;
+    const int ncd = cd.nprim, nPQ = live ? dp.nprim * ncd : 0;
+    int nPQ_all = nPQ;   // uniform trip count over the quartets sharing this wave (the barriers sit in the loop)
+    if (QPW > 1)
+        for (int o = GSZ; o < 64; o <<= 1) nPQ_all = max(nPQ_all, __shfl_xor(nPQ_all, o));
+    const double *prim_b = A.prim + (size_t)dp.prim_off * 8, *prim_k = A.prim + (size_t)cd.prim_off * 8;
+    const double *prim_m = A.prim + (size_t)m_prim * 8;
+    for (int pq0 = 0; pq0 < nPQ_all; pq0 += PB) {
+        const int npq = max(0, min(PB, nPQ - pq0));
+        for (int idx = lane; idx < npq * 2 * n; idx += GSZ) {   // roots and weights
+            const int pql = idx / (2 * n), f = idx - pql * 2 * n;
+            const int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
+            const double *b = prim_b + (size_t)ip * 8, *k = prim_k + (size_t)jp * 8;
+            const double p = b[0], q = k[0];
+            const double dx = b[1] - k[1], dy = b[2] - k[2], dz = b[3] - k[3];
+            rw[pql * 2 * n + f] = rys_eval(A.rys, n, f, p * q / (p + q) * (dx * dx + dy * dy + dz * dz));
+        }
+        if (has_m)
+            for (int idx = lane; idx < npq; idx += GSZ) {       // K- / K+ of the primitive pairs of this batch
+                const int ip = (pq0 + idx) / ncd;
+                rho[idx] = prim_m[(size_t)ip * 8 + 7] / prim_b[(size_t)ip * 8 + 7];
+            }
+        __syncthreads();
+        for (int idx = lane; idx < npq * n * 3; idx += GSZ) {    // 2-D recurrence tables
+            const int pql = idx / (3 * n), rem = idx - pql * 3 * n, r = rem / 3, d = rem - r * 3;
+            const int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
+            const double *b = prim_b + (size_t)ip * 8, *k = prim_k + (size_t)jp * 8;
+            const double p = b[0], q = k[0], pq1 = 1.0 / (p + q);
+            const double u = rw[pql * 2 * n + r];
+            const double PQd = b[1 + d] - k[1 + d];
+            const double b00 = 0.5 * u * pq1, b10 = 0.5 / p * (1.0 - u * q * pq1), b01 = 0.5 / q * (1.0 - u * p * pq1);
+            const double c00 = b[4 + d] - u * q * pq1 * PQd, c01 = k[4 + d] + u * p * pq1 * PQd;
+            double *T = T0 + ((size_t)(pql * n + r) * 3 + d) * tsz;
+            double t00 = 1.0;
+            if (d == 2) t00 = rw[pql * 2 * n + n + r] * b[7] * k[7] * 34.986836655249725 /* 2 pi^2.5 */ * pq1 * sqrt(p + q) / (p * q);
+            T[0] = t00;
+            double tm = 0.0, tc = t00;
+            for (int i = 0; i < A.nmax; i++) {
+                const double tn = c00 * tc + i * b10 * tm;
+                T[(i + 1) * M1] = tn;
+                tm = tc; tc = tn;
+            }
+            for (int m = 0; m < MMAX; m++)
+                for (int i = 0; i <= A.nmax; i++) {
+                    double v = c01 * T[i * M1 + m];
+                    if (m > 0) v += m * b01 * T[i * M1 + m - 1];
+                    if (i > 0) v += i * b00 * T[(i - 1) * M1 + m];
+                    T[i * M1 + m + 1] = v;
+                }
+        }
+        __syncthreads();
+        const int nslot = npq * n;
+        for (int s_ = 0; s_ < nslot; s_++) {
+            const double *Tx = T0 + (size_t)s_ * 3 * tsz, *Ty = Tx + tsz, *Tz = Ty + tsz;
+            const double rs = has_m ? rho[s_ / n] : 0.0;
+#pragma unroll
+            for (int rr = 0; rr < ROWS; rr++) {
+                if (!valid[rr]) continue;
+                double x[M1], y[M1], z[M1];
+                const double sc = minus[rr] ? rs : 1.0;
+#pragma unroll
+                for (int m = 0; m < M1; m++) { x[m] = Tx[bx[rr] + m]; y[m] = Ty[by[rr] + m]; z[m] = Tz[bz[rr] + m] * sc; }
+#pragma unroll
+                for (int f = 0; f < NF; f++) acc[rr][f] = fma(x[FT.fx[f]] * y[FT.fy[f]], z[FT.fz[f]], acc[rr][f]);
+            }
+        }
+        __syncthreads();
+    }
+    double g[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int rr = 0; rr < ROWS; rr++) {
+        if (!valid[rr]) continue;
+        double Yk[NSCD];
+#pragma unroll
+        for (int c = 0; c < NSCD; c++) {
+            double s = 0.0;
+#pragma unroll
+            for (int f = 0; f < NF; f++) s = fma(acc[rr][f], McdL[c * NF + f], s);
+            Yk[c] = s;
+        }
+        const int e = lane + GSZ * rr;
+        const int nev = minus[rr] ? A.ne_m : A.ne_p, el = minus[rr] ? e - A.ne_p : e;
+        const double *Mx = A.Mbuf + (minus[rr] ? m_off_m : dp.m_off) + el;
+        const size_t xs = (size_t)nsab * nev;
+        for (int r = 0; r < nsab; r++) {
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c < NSCD; c++) t = fma(Yk[c], G[r * NSCD + c], t);
+            const size_t o = (size_t)r * nev;
+            g[0] = fma(Mx[o], t, g[0]); g[1] = fma(Mx[xs + o], t, g[1]); g[2] = fma(Mx[2 * xs + o], t, g[2]);
+        }
+    }
+    double w = 4.0;
+    if (dp.sh_i == dp.sh_j) w *= 0.5;
+    if (cd.sh_i == cd.sh_j) w *= 0.5;
+    if (same_pair) w *= 0.5;
+#pragma unroll
+    for (int x = 0; x < 3; x++) {
+        double v = g[x];
+        for (int o = GSZ / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (live && lane == 0) {
+            double *gc = A.grad + (size_t)((blockIdx.x * QPW + grp) & (GRAD_COPIES - 1)) * A.natm3;
+            atomicAdd(&gc[A.shell_atom[dp.sh_i] * 3 + x], w * v);
+            atomicAdd(&gc[A.shell_atom[A.inv_from_second ? dp.sh_j : cd.sh_i] * 3 + x], -w * v);
+        }
+    }
+}
+
+// rows per lane and lanes per quartet by the number of rows ne of the two derivative blocks:
+//   ne <= 64: (2, 32), two quartets per wave   ne <= 128: (2, 64)   ne <= 192: (3, 64)
+// Measured on one box (ibuprofen/def2-TZVP, grad_dtol 1e-10, whole two-electron gradient): pipeline only 0.535 s; row kernel for
+// ne > 64 only 0.504; for ne >= 33 0.495 (one quartet per wave there: 0.502); for ne >= 20 0.492; four quartets per wave
+// (16 lanes) for ne <= 32: 0.518 -- the small blocks stay on the hand-over pipeline / thread-per-quartet kernels.
+struct RowsGeom { int rows, gsz; };
+static RowsGeom rows_geometry(int ne)
+{
+    if (g_rows_g32 && ne <= 64) return {2, 32};
+    if (ne <= 64) return {1, 64};
+    if (ne <= 128) return {2, 64};
+    if (ne <= 192) return {3, 64};
+    return {0, 0};
+}
+template <int LC, int LD, int ROWS, int GSZ>
+static int launch_grad_rows_g(const GradRowsArgs &R, size_t shm_per_quartet, hipStream_t st)
+{
+    constexpr int QPW = 64 / GSZ;
+    const size_t shm = shm_per_quartet * QPW;
+    if (shm > 160 * 1024) return 0;
+    if (shm > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)eri_grad_rows_kernel<LC, LD, ROWS, GSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((eri_grad_rows_kernel<LC, LD, ROWS, GSZ>), dim3((unsigned)((R.ntask + QPW - 1) / QPW)), dim3(64), shm, st, R);
+    HIPCHK(hipGetLastError());
+    return 1;
+}
+template <int LC, int LD>
+static int launch_grad_rows_t(RowsGeom gm, const GradRowsArgs &R, size_t shm_q, hipStream_t st)
+{
+    if (gm.rows == 2 && gm.gsz == 32) return launch_grad_rows_g<LC, LD, 2, 32>(R, shm_q, st);
+    if (gm.rows == 1 && gm.gsz == 64) return launch_grad_rows_g<LC, LD, 1, 64>(R, shm_q, st);
+    if (gm.rows == 2 && gm.gsz == 64) return launch_grad_rows_g<LC, LD, 2, 64>(R, shm_q, st);
+    if (gm.rows == 3 && gm.gsz == 64) return launch_grad_rows_g<LC, LD, 3, 64>(R, shm_q, st);
+    return 0;
+}
+// 1: launched, 0: no row kernel for this (other pair, number of rows), -1: error.  dry: only answers the question.
+static int launch_grad_rows(int lc, int ld, int ne, const GradRowsArgs &R, size_t shm_q, hipStream_t st, bool dry = false)
+{
+    const RowsGeom gm = rows_geometry(ne);
+    if (gm.rows == 0) return 0;
+#define ROWS_CASE(a, b) if (lc == a && ld == b) return dry ? 1 : launch_grad_rows_t<a, b>(gm, R, shm_q, st)
+    ROWS_CASE(0, 0); ROWS_CASE(1, 0); ROWS_CASE(1, 1); ROWS_CASE(2, 0); ROWS_CASE(2, 1); ROWS_CASE(2, 2); ROWS_CASE(3, 0); ROWS_CASE(3, 1);
+#undef ROWS_CASE
+    return 0;
+}
+
+// =================================================================================================
 // Derivative ERIs contracted with the two-particle density, LOW angular classes: one THREAD per (canonical quartet, role
 // permutation), everything in registers (the gradient counterpart of eri_tpq_kernel; round 1 spent 1.6 of the 1.9 s of the
 // ibuprofen/def2-TZVP gradient in the wave-per-quartet path of these classes).
@@ -5946,6 +6222,42 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 if (has_m) {
                     Em.bra = Dc.d_g_recs[orient][1]; Em.ket = Oc.d_recs; Em.prim = c->d_prim; Em.prefix = d_prefix; Em.nbra = Ep.nbra;
                     Em.comp = d_comp_m; Em.work = d_wm; Em.rys = c->rys; Em.diag = 0; Em.swap = Ep.swap;
+                }
+                if (c->opt_grad_rows) {   // row kernel: no hand-over, one launch (see eri_grad_rows_kernel)
+                    const int ne_p = ne_of(l1 + 1, l2), ne_m = has_m ? ne_of(l1 - 1, l2) : 0, ne_all = ne_p + ne_m;
+                    GradRowsArgs R{};
+                    if (ne_all >= c->opt_grad_rows_min && launch_grad_rows(lc, ldd, ne_all, R, 0, st, true) == 1) {
+                        R.dplus = Dc.d_g_recs[orient][0]; R.dminus = has_m ? Dc.d_g_recs[orient][1] : nullptr; R.ket = Oc.d_recs;
+                        R.prim = c->d_prim; R.Mbuf = c->d_M; R.tasks = tasks_w; R.prefix = d_prefix; R.nbra = (int)B.recs.size();
+                        const int64_t lo_t = ntask_w * rank / nranks, hi_t = ntask_w * (rank + 1) / nranks;
+                        R.t0 = lo_t; R.ntask = hi_t - lo_t;
+                        R.swap = swap ? 1 : 0; R.same_class = (bc == kc);
+                        const RowsGeom gm = rows_geometry(ne_all);
+                        R.nmax = Ep.nmax; R.nroots = Ep.nroots; R.tsz = Ep.tsz; R.PB = std::max(1, gm.gsz / (3 * Ep.nroots));
+                        R.ne_p = ne_p; R.ne_m = ne_m; R.nsab = (2 * l1 + 1) * (2 * l2 + 1); R.ns2 = 2 * l2 + 1;
+                        R.comp_p = d_comp_p; R.comp_m = d_comp_m; R.rys = c->rys;
+                        R.D = c->d_Dpad; R.Dm = d_Mpad; R.ld = c->ldp; R.hyb = hyb; R.shell_atom = d_shell_atom; R.grad = d_gcopies; R.natm3 = natm3;
+                        R.inv_from_second = swap ? 0 : 1;
+                        R.q_bra = Dc.d_q; R.q_ket = Oc.d_q; R.dmax = dmax_w; R.nbas_d = c->nbas; R.dtol = c->opt_grad_dtol;
+                        const int nscd_ = Oc.nsab, nf_ = Oc.ne;
+                        const size_t shm_q = sizeof(double) * ((size_t)R.PB * R.nroots * 3 * R.tsz + (size_t)R.PB * 2 * R.nroots + (size_t)R.PB +
+                                                               (size_t)nscd_ * nf_ + (size_t)R.nsab * nscd_);
+                        if (R.ntask < ((int64_t)1 << 31)) {
+                            const bool dbgr = getenv("MI355_DEBUG") != nullptr;
+                            auto tr0 = std::chrono::steady_clock::now();
+                            if (dbgr) hipStreamSynchronize(st);
+                            const int used = R.ntask > 0 ? launch_grad_rows(lc, ldd, ne_all, R, shm_q, st) : 1;
+                            if (used < 0) return -1;
+                            if (used) {
+                                if (dbgr) {
+                                    hipStreamSynchronize(st);
+                                    fprintf(stderr, "[mi355] grad class (%d%d|%d%d) perm %d: %ld quartets, %.4f s (row kernel, %d rows x %d lanes)\n", l1, l2, lc,
+                                            ldd, perm, (long)ntask_w, std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count(), gm.rows, gm.gsz);
+                                }
+                                continue;
+                            }
+                        }
+                    }
                 }
                 Ep.tasks = Em.tasks = tasks_w;
                 Ep.prim_lds = Em.prim_lds = (c->opt_prim_lds && B.max_np + Kc.max_np <= 160) ? B.max_np + Kc.max_np : 0;
