@@ -5583,12 +5583,23 @@ __global__ __launch_bounds__(64) void eri_grad_rows_kernel(GradRowsArgs A)
         const int nev = minus[rr] ? A.ne_m : A.ne_p, el = minus[rr] ? e - A.ne_p : e;
         const double *Mx = A.Mbuf + (minus[rr] ? m_off_m : dp.m_off) + el;
         const size_t xs = (size_t)nsab * nev;
-        for (int r = 0; r < nsab; r++) {
-            double t = 0.0;
+        // the derivative-matrix elements of four r go out together (they depend on nothing computed here): one round trip per
+        // four rows of G instead of one per row
+        for (int r0 = 0; r0 < nsab; r0 += 4) {
+            double mx[4][3];
 #pragma unroll
-            for (int c = 0; c < NSCD; c++) t = fma(Yk[c], G[r * NSCD + c], t);
-            const size_t o = (size_t)r * nev;
-            g[0] = fma(Mx[o], t, g[0]); g[1] = fma(Mx[xs + o], t, g[1]); g[2] = fma(Mx[2 * xs + o], t, g[2]);
+            for (int u = 0; u < 4; u++) {
+                const size_t o = (size_t)min(r0 + u, nsab - 1) * nev;
+                mx[u][0] = Mx[o]; mx[u][1] = Mx[xs + o]; mx[u][2] = Mx[2 * xs + o];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (r0 + u >= nsab) break;
+                double t = 0.0;
+#pragma unroll
+                for (int c = 0; c < NSCD; c++) t = fma(Yk[c], G[(r0 + u) * NSCD + c], t);
+                g[0] = fma(mx[u][0], t, g[0]); g[1] = fma(mx[u][1], t, g[1]); g[2] = fma(mx[u][2], t, g[2]);
+            }
         }
     }
     double w = 4.0;
