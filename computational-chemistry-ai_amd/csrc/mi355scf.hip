@@ -6127,7 +6127,8 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
             }
             HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
             const TaskIdx *tasks_dev = nullptr;
-            if (c->opt_task_table && ntask >= 65536) {   // up to 3 permutations x 3 launches walk this task list
+            const bool live_ok = d_dmax && c->opt_grad_live && ntask >= 4096 && ntask <= ((int64_t)1 << 28);   // see ensure_live below
+            if (c->opt_task_table && ntask >= 65536 && ntask <= ((int64_t)1 << 28) && !live_ok) {   // up to 3 permutations x 3 launches walk this task list
                 if ((size_t)ntask > tasks_cap) {
                     if (d_tasks) hipFree(d_tasks);
                     tasks_cap = (size_t)ntask + (size_t)ntask / 4;
@@ -6141,7 +6142,8 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
             // live_fill_kernel); built on first need -- classes wholly on the thread-per-quartet path never ask for it
             int64_t nlive = -1;
             auto ensure_live = [&]() -> int {
-                if (nlive >= 0 || !d_dmax || !c->opt_grad_live || ntask < 4096) return 0;
+                // (lists beyond 2^28 quartets -- 2 GB -- are not built: those launches screen per wave as before)
+                if (nlive >= 0 || !live_ok) return 0;
                 const int nblk = (int)((ntask + 255) / 256);
                 if ((size_t)nblk + 1 > live_cap) {
                     if (d_live_counts) hipFree(d_live_counts);
