@@ -171,3 +171,41 @@ def test_rhf_gradient_matches_cpu_oracle_finite_difference():
                 e.append(orc.rhf(mol.set_geom_(Rn, unit="Bohr", inplace=False), conv_tol=1e-12)["e_tot"])
             ref[ia, x] = (e[0] - e[1]) / (2 * h)
     assert np.abs(g - ref).max() < 2e-6, (g, ref)
+
+
+@pytest.mark.parametrize("spin", [0, 1])
+def test_gradient_paths_agree(spin):
+    """The two-electron gradient through its three routes for the mid / high classes -- row kernel on the live-quartet list
+    (default), hand-over pipeline on the live list, hand-over pipeline screening per wave (round-2 path) -- on benzene/cc-pVTZ
+    (f shells, all 55 class pairs) with a converged density; closed shell and the spin-density form of the cation."""
+    from mi355scf import fixtures
+    from mi355scf.mole import Mole
+    from mi355scf.scf import RHF
+    from mi355scf.uhf import UHF
+    mol = Mole(atom=fixtures.BENZENE, basis="cc-pVTZ", verbose=0, charge=spin, spin=spin).build()
+    mf = (UHF if spin else RHF)(mol)
+    mf.conv_tol = 1e-10
+    mf.kernel()
+    eng = mf.engine
+    if spin:
+        D = (mf._dm[0] + mf._dm[1]).contiguous()
+        M = (mf._dm[0] - mf._dm[1]).contiguous()
+    else:
+        D, M = mf._dm.contiguous(), None
+    out = {}
+    for name, opts in (("rows+live", {"grad_rows": 1, "grad_live": 1}), ("pipeline+live", {"grad_rows": 0, "grad_live": 1}),
+                       ("pipeline", {"grad_rows": 0, "grad_live": 0}), ("rows", {"grad_rows": 1, "grad_live": 0})):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        for dtol in (1e-13, 1e-10):
+            eng.set_option("grad_dtol", dtol)
+            g = torch.zeros(mol.natm, 3, dtype=torch.float64, device=eng.device)
+            eng.grad_eri(D, 1.0, g, spin_density=M)
+            out[(name, dtol)] = g.cpu().numpy()
+    eng.set_option("grad_rows", 1); eng.set_option("grad_live", 1); eng.set_option("grad_dtol", 1e-13)
+    ref = out[("pipeline", 1e-13)]
+    assert np.abs(ref).max() > 1.0
+    for (name, dtol), g in out.items():
+        # same quartets, different summation order (1e-13); the looser threshold drops quartets worth < 1e-10 each (4e-7 in all here)
+        assert np.abs(g - out[("pipeline", dtol)]).max() < 1e-10, (name, dtol, np.abs(g - out[("pipeline", dtol)]).max())
+        assert np.abs(g - ref).max() < (1e-10 if dtol == 1e-13 else 1e-6), (name, dtol)
