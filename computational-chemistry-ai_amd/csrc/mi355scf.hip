@@ -326,8 +326,6 @@ struct mi_ctx {
     int opt_tri_tiles = 1;   // block-diagonal tiles store triangular rows (0: the full-row layout of round 1); next mi_eri_prepare
     int tri = 1;             // layout of the current store
     int opt_jk_cache_mb = 160; // MiB of tiles read with the default cache policy when the tensor exceeds the Infinity Cache (0: none)
-    int opt_eri_rows = 1;    // evaluation: row kernel (eri_rows_kernel) for the classes it covers
-    int opt_eri_rows_min = 10;   // ... when the bra block has at least this many rows
     int opt_grad_rows = 1;   // gradient: row kernel (eri_grad_rows_kernel) for the classes it covers
     int opt_grad_rows_min = 20;  // ... when the two derivative blocks have at least this many rows
     int opt_grad_live = 1;   // gradient: wave-per-quartet launches walk the compacted list of density-screened quartets
@@ -587,8 +585,6 @@ extern "C" int mi_set_option(mi_ctx *c, const char *key, double value)
     else if (k == "jk_kjlt") c->opt_jk_kjlt = (int)value;
     else if (k == "grad_live") c->opt_grad_live = (int)value;
     else if (k == "grad_rows") c->opt_grad_rows = (int)value;
-    else if (k == "eri_rows") c->opt_eri_rows = (int)value;
-    else if (k == "eri_rows_min") c->opt_eri_rows_min = (int)value;
     else if (k == "grad_rows_min") c->opt_grad_rows_min = (int)value;
     else if (k == "grad_rows_g32") g_rows_g32 = (int)value;
     else if (k == "jk_cache_mb") c->opt_jk_cache_mb = (int)value;
@@ -1500,8 +1496,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 // Fused evaluation of the mid / high classes: Rys quadrature, HRR + cart->sph products and the scatter of one quartet in ONE wave
 // and ONE launch (round 3).  FMAXC = [e0|f0] components per lane kept in registers during the primitive loop.
 struct FusedArgs { XfArgs X; EriArgs R; };
-struct EriRowsArgs { XfArgs X; EriArgs R; };   // eri_rows_kernel (defined with the row gradient kernel below)
-static int launch_eri_rows(int lc, int ld, EriRowsArgs &P, hipStream_t st, bool dry);
 template <bool MFMA, int FMAXC>
 __global__ __launch_bounds__(64) void eri_fused_kernel(FusedArgs F)
 {
@@ -2553,32 +2547,6 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                                 Kc.la, Kc.lb, (long)ntask, t_rys, t_rys / ntask * 1e9);
                     }
                     continue;
-                }
-            }
-            if (c->opt_eri_rows && !E.diag && X.ne >= c->opt_eri_rows_min) {   // row kernel: one launch, no hand-over buffer (eri_rows_kernel)
-                EriRowsArgs P;
-                P.X = X; P.R = E;
-                P.R.prim_lds = 0; P.R.own_table = nullptr; P.R.qtol = 0.0; P.R.dmax = nullptr;   // (screening as in the transform half: check_owner, qtol)
-                P.X.m_lds = 0;
-                if (launch_eri_rows(Kc.la, Kc.lb, P, st, true) == 1) {
-                    auto ta = std::chrono::steady_clock::now();
-                    if (dbg) hipStreamSynchronize(st);
-                    int used = 1;
-                    for (int64_t t0 = 0; t0 < ntask && used == 1; t0 += (int64_t)1 << 30) {
-                        const int64_t nb = std::min<int64_t>((int64_t)1 << 30, ntask - t0);
-                        P.X.t0 = t0; P.X.ntask = nb; P.X.xcd = nb >= 2048 ? xcd_wave : 0u;
-                        used = launch_eri_rows(Kc.la, Kc.lb, P, st, false);
-                        if (used < 0) return -1;
-                    }
-                    if (used == 1) {
-                        if (dbg) {
-                            hipStreamSynchronize(st);
-                            t_rys = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
-                            fprintf(stderr, "[mi355] eri class (%d%d|%d%d): %ld quartets, row kernel %.4f s (%.2f ns/q)\n", B.la, B.lb, Kc.la, Kc.lb,
-                                    (long)ntask, t_rys, t_rys / ntask * 1e9);
-                        }
-                        continue;
-                    }
                 }
             }
             if (c->opt_eri_fused && !E.diag) {
@@ -5444,259 +5412,6 @@ struct FTab {
                 for (int b = f - a; b >= 0; b--) { fx[n] = a; fy[n] = b; fz[n] = f - a - b; n++; }
     }
 };
-
-// =================================================================================================
-// ERI EVALUATION with the same row layout (round 3): one launch per class pair, no hand-over buffer.  Lane e owns row e of the
-// contracted [e0|f0] block (ket class compile time, NF elements in registers), transforms it on the ket side where it lives
-// (Yk[c] = sum_f E0[e][f] Mcd[c][f]) and leaves Yk in LDS; the bra side is one small product O = Mab . Yk (FP64 MFMA for the
-// large classes) and O goes to the tiles through the address-ordered scatter of eri_transform_scatter (code repeated here
-// rather than shared, so that the tuned hand-over kernel keeps its register allocation).
-// =================================================================================================
-template <int LC, int LD, int ROWS, int GSZ>
-__global__ __launch_bounds__(64) void eri_rows_kernel(EriRowsArgs P)
-{
-    const XfArgs &A = P.X;
-    const EriArgs &R = P.R;
-    constexpr int NF = c_ne(LC, LD), MMAX = LC + LD, M1 = MMAX + 1;
-    constexpr int NSC = 2 * LC + 1, NSD = 2 * LD + 1, NSCD = NSC * NSD;
-    constexpr int QPW = 64 / GSZ;
-    constexpr FTab<LC, LD> FT{};
-    extern __shared__ double lds_all[];
-    __shared__ int64_t tbase_all[QPW][8][16];
-    const int grp = QPW == 1 ? 0 : threadIdx.x / GSZ, lane = QPW == 1 ? threadIdx.x : threadIdx.x % GSZ;
-    const int64_t tl = (int64_t)xcd_block(blockIdx.x, A.xcd) * QPW + grp;
-    bool live = tl < A.ntask;
-    int ib, ik;
-    get_task(A.tasks, A.prefix, A.nbra, A.t0 + (live ? tl : 0), ib, ik);
-    const PairRec ab = A.bra[ib], cd = A.ket[ik];
-    if (A.qtol > 0.0 && A.q_bra[ib] * A.q_ket[ik] < A.qtol) live = false;
-    if (A.check_owner)
-        live = quartet_has_resident_tile(A.tile_table, ab.ao_i, A.ni, ab.ao_j, A.nj, cd.ao_i, A.nk, cd.ao_j, A.nl, lane, GSZ, grp) && live;
-    if (QPW == 1 && !live) return;
-    const int n = R.nroots, tsz = R.tsz, PB = R.PB, nsab = A.nsab, ne = A.ne;
-    const size_t lds_per = (size_t)PB * n * 3 * tsz + (size_t)PB * 2 * n + NSCD * NF + (size_t)ne * NSCD + (size_t)nsab * NSCD;
-    double *T0 = lds_all + (size_t)grp * lds_per;          // [PB n][3][tsz]
-    double *rw = T0 + (size_t)PB * n * 3 * tsz;            // [PB][2 n]
-    double *McdL = rw + (size_t)PB * 2 * n;                // [NSCD][NF]
-    double *YL = McdL + NSCD * NF;                         // [ne][NSCD]
-    double *O = YL + (size_t)ne * NSCD;                    // [nsab][NSCD]
-    if (live) {
-        const double *Mcd = A.Mbuf + cd.m_off;
-        for (int q = lane; q < NSCD * NF; q += GSZ) McdL[q] = Mcd[q];
-    }
-    // symmetry images and tile bases of the 2x2x2x2 sub-blocks (as in xf_body)
-    const int nsh[4] = {A.nsab / A.nsb, A.nsb, NSC, NSD};
-    const int aos[4] = {ab.ao_i, ab.ao_j, cd.ao_i, cd.ao_j};
-    int lo[4], hi[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) { lo[q] = aos[q] >> 3; hi[q] = (aos[q] + nsh[q] - 1) >> 3; }
-    auto ok = [&](int a, int b, int c, int d) { return hi[a] >= lo[b] && hi[c] >= lo[d]; };
-    const unsigned mask = (ok(0, 1, 2, 3) ? 1u : 0u) | (ok(1, 0, 2, 3) ? 2u : 0u) | (ok(0, 1, 3, 2) ? 4u : 0u) | (ok(1, 0, 3, 2) ? 8u : 0u) |
-                          (ok(2, 3, 0, 1) ? 16u : 0u) | (ok(3, 2, 0, 1) ? 32u : 0u) | (ok(2, 3, 1, 0) ? 64u : 0u) | (ok(3, 2, 1, 0) ? 128u : 0u);
-    int64_t (*tbase)[16] = tbase_all[grp];
-    if (live) {
-        for (int idx = lane; idx < 128; idx += GSZ) {
-            const int img = idx >> 4;
-            int64_t base = -1;
-            if (mask & (1u << img)) {
-                int blk[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) blk[q] = lo[q] + ((idx >> q) & 1);
-                const bool valid = blk[0] <= hi[0] && blk[1] <= hi[1] && blk[2] <= hi[2] && blk[3] <= hi[3];
-                const int f = img == 5 ? 6 : (img == 6 ? 5 : img);
-                int r0 = (f & 1) ? 1 : 0, r1 = (f & 1) ? 0 : 1, r2 = (f & 2) ? 3 : 2, r3 = (f & 2) ? 2 : 3;
-                if (f & 4) { int t_ = r0; r0 = r2; r2 = t_; t_ = r1; r1 = r3; r3 = t_; }
-                const int I = blk[r0], J = blk[r1], K = blk[r2], L = blk[r3];
-                if (valid && I >= J && K >= L) {
-                    const int bij = I * (I + 1) / 2 + J, bkl = K * (K + 1) / 2 + L;
-                    if (bij >= bkl) {
-                        const int32_t t = A.tile_table[(size_t)bij * (bij + 1) / 2 + bkl];
-                        if (t >= 0) base = A.tile_off[t];
-                    }
-                }
-            }
-            tbase[img][idx & 15] = base;
-        }
-    }
-    int bx[ROWS], by[ROWS], bz[ROWS];
-    bool valid[ROWS];
-#pragma unroll
-    for (int rr = 0; rr < ROWS; rr++) {
-        const int e = lane + GSZ * rr;
-        valid[rr] = live && e < ne;
-        const uint32_t w = valid[rr] ? R.comp[(size_t)e * NF] : 0u;
-        bx[rr] = (int)(w & 1023u) - LC; by[rr] = (int)((w >> 10) & 1023u); bz[rr] = (int)((w >> 20) & 1023u);
-    }
-    double acc[ROWS][NF];
-#pragma unroll
-    for (int rr = 0; rr < ROWS; rr++)
-#pragma unroll
-        for (int f = 0; f < NF; f++) acc[rr][f] = 0.0;
-    const int ncd = cd.nprim, nPQ = live ? ab.nprim * ncd : 0;
-    int nPQ_all = nPQ;
-    if (QPW > 1)
-        for (int o = GSZ; o < 64; o <<= 1) nPQ_all = max(nPQ_all, __shfl_xor(nPQ_all, o));
-    const double *prim_b = R.prim + (size_t)ab.prim_off * 8, *prim_k = R.prim + (size_t)cd.prim_off * 8;
-    for (int pq0 = 0; pq0 < nPQ_all; pq0 += PB) {
-        const int npq = max(0, min(PB, nPQ - pq0));
-        for (int idx = lane; idx < npq * 2 * n; idx += GSZ) {   // roots and weights
-            const int pql = idx / (2 * n), f = idx - pql * 2 * n;
-            const int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
-            const double *b = prim_b + (size_t)ip * 8, *k = prim_k + (size_t)jp * 8;
-            const double p = b[0], q = k[0];
-            const double dx = b[1] - k[1], dy = b[2] - k[2], dz = b[3] - k[3];
-            rw[pql * 2 * n + f] = rys_eval(R.rys, n, f, p * q / (p + q) * (dx * dx + dy * dy + dz * dz));
-        }
-        __syncthreads();
-        for (int idx = lane; idx < npq * n * 3; idx += GSZ) {    // 2-D recurrence tables
-            const int pql = idx / (3 * n), rem = idx - pql * 3 * n, r = rem / 3, d = rem - r * 3;
-            const int pq = pq0 + pql, ip = pq / ncd, jp = pq - ip * ncd;
-            const double *b = prim_b + (size_t)ip * 8, *k = prim_k + (size_t)jp * 8;
-            const double p = b[0], q = k[0], pq1 = 1.0 / (p + q);
-            const double u = rw[pql * 2 * n + r];
-            const double PQd = b[1 + d] - k[1 + d];
-            const double b00 = 0.5 * u * pq1, b10 = 0.5 / p * (1.0 - u * q * pq1), b01 = 0.5 / q * (1.0 - u * p * pq1);
-            const double c00 = b[4 + d] - u * q * pq1 * PQd, c01 = k[4 + d] + u * p * pq1 * PQd;
-            double *T = T0 + ((size_t)(pql * n + r) * 3 + d) * tsz;
-            double t00 = 1.0;
-            if (d == 2) t00 = rw[pql * 2 * n + n + r] * b[7] * k[7] * 34.986836655249725 /* 2 pi^2.5 */ * pq1 * sqrt(p + q) / (p * q);
-            T[0] = t00;
-            double tm = 0.0, tc = t00;
-            for (int i = 0; i < R.nmax; i++) {
-                const double tn = c00 * tc + i * b10 * tm;
-                T[(i + 1) * M1] = tn;
-                tm = tc; tc = tn;
-            }
-            for (int m = 0; m < MMAX; m++)
-                for (int i = 0; i <= R.nmax; i++) {
-                    double v = c01 * T[i * M1 + m];
-                    if (m > 0) v += m * b01 * T[i * M1 + m - 1];
-                    if (i > 0) v += i * b00 * T[(i - 1) * M1 + m];
-                    T[i * M1 + m + 1] = v;
-                }
-        }
-        __syncthreads();
-        const int nslot = npq * n;
-        for (int s_ = 0; s_ < nslot; s_++) {
-            const double *Tx = T0 + (size_t)s_ * 3 * tsz, *Ty = Tx + tsz, *Tz = Ty + tsz;
-#pragma unroll
-            for (int rr = 0; rr < ROWS; rr++) {
-                if (!valid[rr]) continue;
-                double x[M1], y[M1], z[M1];
-#pragma unroll
-                for (int m = 0; m < M1; m++) { x[m] = Tx[bx[rr] + m]; y[m] = Ty[by[rr] + m]; z[m] = Tz[bz[rr] + m]; }
-#pragma unroll
-                for (int f = 0; f < NF; f++) acc[rr][f] = fma(x[FT.fx[f]] * y[FT.fy[f]], z[FT.fz[f]], acc[rr][f]);
-            }
-        }
-        __syncthreads();
-    }
-    // ket side of every row, in place; the rows meet in LDS
-#pragma unroll
-    for (int rr = 0; rr < ROWS; rr++) {
-        if (!valid[rr]) continue;
-        const int e = lane + GSZ * rr;
-#pragma unroll
-        for (int c = 0; c < NSCD; c++) {
-            double s = 0.0;
-#pragma unroll
-            for (int f = 0; f < NF; f++) s = fma(acc[rr][f], McdL[c * NF + f], s);
-            YL[e * NSCD + c] = s;
-        }
-    }
-    __syncthreads();
-    // bra side: O[r][c] = sum_e Mab[r][e] Yk[e][c]
-    const double *Mab = A.Mbuf + ab.m_off;
-    if (GSZ == 64 && mfma_worthwhile(nsab, NSCD, ne)) {
-        for (int m0 = 0; m0 < nsab; m0 += 16)
-            for (int n0 = 0; n0 < NSCD; n0 += 16) {
-                d4_t o4 = wave_mfma_tile(Mab, ne, 1, nsab, YL, NSCD, 1, NSCD, ne, m0, n0, lane);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int r = m0 + (lane >> 4) + 4 * q, c = n0 + (lane & 15);
-                    if (r < nsab && c < NSCD) O[r * NSCD + c] = o4[q];
-                }
-            }
-    } else if (live) {
-        for (int o = lane; o < nsab * NSCD; o += GSZ) {
-            const int r = o / NSCD, c = o - r * NSCD;
-            double s = 0.0;
-            for (int e = 0; e < ne; e++) s = fma(Mab[r * ne + e], YL[e * NSCD + c], s);
-            O[o] = s;
-        }
-    }
-    __syncthreads();
-    if (!live) return;
-    // address-ordered scatter, one symmetry image at a time (see xf_body)
-    {
-        const int n0_ = nsh[0], n1_ = nsh[1], n2_ = nsh[2], n3_ = nsh[3];
-#pragma unroll 1
-        for (int img = 0; img < 8; img++) {
-            if (!(mask & (1u << img))) continue;
-            const int ri = (0x32321010 >> (4 * img)) & 3, rj = (0x23230101 >> (4 * img)) & 3;
-            const int rk = (0x11003322 >> (4 * img)) & 3, rl = (0x00112233 >> (4 * img)) & 3;
-            auto pick = [](int a, int b, int c_, int d, int q) { return q == 0 ? a : (q == 1 ? b : (q == 2 ? c_ : d)); };
-            const int Ni = pick(n0_, n1_, n2_, n3_, ri), Nj = pick(n0_, n1_, n2_, n3_, rj), Nk = pick(n0_, n1_, n2_, n3_, rk),
-                      Nl = pick(n0_, n1_, n2_, n3_, rl);
-            const int Ai = pick(aos[0], aos[1], aos[2], aos[3], ri), Aj = pick(aos[0], aos[1], aos[2], aos[3], rj),
-                      Ak = pick(aos[0], aos[1], aos[2], aos[3], rk), Al = pick(aos[0], aos[1], aos[2], aos[3], rl);
-            const int p0 = Al >> 1, npair = ((Al + Nl - 1) >> 1) - p0 + 1;
-            const int row = Ni * Nk * 2, tot = Nj * npair * row;
-            const float inv_row = 1.0f / (float)row, inv_nk = 1.0f / (float)Nk, inv_np = 1.0f / (float)npair;
-            const int st_a = n1_ * NSCD, st_b = NSCD, st_c = n3_, st_d = 1;
-            const int Si = pick(st_a, st_b, st_c, st_d, ri), Sj = pick(st_a, st_b, st_c, st_d, rj), Sk = pick(st_a, st_b, st_c, st_d, rk),
-                      Sl = pick(st_a, st_b, st_c, st_d, rl);
-            const int Li = pick(lo[0], lo[1], lo[2], lo[3], ri), Lj = pick(lo[0], lo[1], lo[2], lo[3], rj), Lk = pick(lo[0], lo[1], lo[2], lo[3], rk),
-                      Ll = pick(lo[0], lo[1], lo[2], lo[3], rl);
-            for (int e = lane; e < tot; e += GSZ) {
-                int t = (int)(((float)e + 0.5f) * inv_row);
-                const int w = e - t * row;
-                const int par = w & 1, h = w >> 1;
-                const int ia = (int)(((float)h + 0.5f) * inv_nk), kc = h - ia * Nk;
-                const int jb = (int)(((float)t + 0.5f) * inv_np), mp = t - jb * npair;
-                const int labs = ((p0 + mp) << 1) + par;
-                if (labs < Al || labs >= Al + Nl) continue;
-                const double v = O[ia * Si + jb * Sj + kc * Sk + (labs - Al) * Sl];
-                const int gi = Ai + ia, gj = Aj + jb, gk = Ak + kc, gl = labs;
-                const int sub = (((gi >> 3) - Li) << ri) | (((gj >> 3) - Lj) << rj) | (((gk >> 3) - Lk) << rk) | (((gl >> 3) - Ll) << rl);
-                put_tile_at(A, tbase[img][sub], gi, gj, gk, gl, v);
-            }
-        }
-    }
-}
-
-template <int LC, int LD, int ROWS, int GSZ>
-static int launch_eri_rows_g(EriRowsArgs &P, hipStream_t st)
-{
-    constexpr int QPW = 64 / GSZ, NF = c_ne(LC, LD), NSCD = (2 * LC + 1) * (2 * LD + 1);
-    P.R.PB = std::max(1, GSZ / (3 * P.R.nroots));
-    const size_t shm = sizeof(double) * QPW * ((size_t)P.R.PB * P.R.nroots * 3 * P.R.tsz + (size_t)P.R.PB * 2 * P.R.nroots + (size_t)NSCD * NF +
-                                               (size_t)P.X.ne * NSCD + (size_t)P.X.nsab * NSCD);
-    if (shm > 160 * 1024) return 0;
-    if (shm > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void *)eri_rows_kernel<LC, LD, ROWS, GSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL((eri_rows_kernel<LC, LD, ROWS, GSZ>), dim3(eri_grid((P.X.ntask + QPW - 1) / QPW, P.X.xcd)), dim3(64), shm, st, P);
-    HIPCHK(hipGetLastError());
-    return 1;
-}
-template <int LC, int LD>
-static int launch_eri_rows_t(EriRowsArgs &P, hipStream_t st)
-{
-    const int ne = P.X.ne;
-    if (ne <= 64 && g_rows_g32) return launch_eri_rows_g<LC, LD, 2, 32>(P, st);
-    if (ne <= 64) return launch_eri_rows_g<LC, LD, 1, 64>(P, st);
-    if (ne <= 128) return launch_eri_rows_g<LC, LD, 2, 64>(P, st);
-    return 0;
-}
-// 1: launched, 0: no row kernel for this ket class / block size, -1: error.  dry: only answers the question.
-static int launch_eri_rows(int lc, int ld, EriRowsArgs &P, hipStream_t st, bool dry)
-{
-    if (P.X.ne > 128) return 0;
-#define EROWS_CASE(a, b) if (lc == a && ld == b) return dry ? 1 : launch_eri_rows_t<a, b>(P, st)
-    EROWS_CASE(0, 0); EROWS_CASE(1, 0); EROWS_CASE(1, 1); EROWS_CASE(2, 0); EROWS_CASE(2, 1); EROWS_CASE(2, 2); EROWS_CASE(3, 0); EROWS_CASE(3, 1);
-#undef EROWS_CASE
-    return 0;
-}
 
 struct GradRowsArgs {
     const PairRec *dplus, *dminus, *ket;
