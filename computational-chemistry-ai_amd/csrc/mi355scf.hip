@@ -21,6 +21,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mi355scf.h"
@@ -519,8 +520,57 @@ static void arena_give(int dev, double *p, int64_t doubles)
     a.ptr = p; a.doubles = doubles;
 }
 
+// Scratch buffers that every mi_eri_prepare / mi_grad_eri of a geometry optimisation would otherwise allocate and free again
+// (2 GB hand-over buffer, 2 x 1 GB for the gradient, task lists of a few hundred MB): kept per device between calls.  One slot
+// per purpose; a slot that is in use (a second context working on the same device from another thread) is not shared -- the
+// caller then gets a private allocation that is freed on return.  hipMalloc / hipFree of these sizes cost 30-150 ms per
+// geometry step on the slower boxes of the pool.
+enum { SCR_EVAL_WORK = 0, SCR_EVAL_TASKS, SCR_GRAD_WP, SCR_GRAD_WM, SCR_GRAD_TASKS, SCR_GRAD_LIVE, SCR_NSLOT };
+struct ScratchSlot { void *p = nullptr; size_t bytes = 0; bool busy = false; };
+static ScratchSlot g_scratch[16][SCR_NSLOT];
+static std::mutex g_scratch_mu;
+struct Scratch {   // RAII handle of one slot (or of a private allocation)
+    int dev = 0, slot = -1;
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool cached = false;
+    ~Scratch() { release(); }
+    // at least `need` bytes, contents undefined; grows by 25 % when it has to (a grown cached slot stays grown)
+    int ensure(int dev_, int slot_, size_t need)
+    {
+        if (p && bytes >= need) return 0;
+        if (slot < 0) {
+            dev = dev_; slot = slot_;
+            std::lock_guard<std::mutex> g(g_scratch_mu);
+            ScratchSlot &S = g_scratch[dev & 15][slot];
+            if (!S.busy) { S.busy = true; cached = true; p = S.p; bytes = S.bytes; }
+        }
+        if (p && bytes >= need) return 0;
+        if (p) { hipFree(p); p = nullptr; bytes = 0; }
+        if (cached) { std::lock_guard<std::mutex> g(g_scratch_mu); g_scratch[dev & 15][slot].p = nullptr; g_scratch[dev & 15][slot].bytes = 0; }
+        const size_t want = need + need / 4;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return fail("out of device memory for a %zu-byte scratch buffer", want); }
+        bytes = want;
+        if (cached) { std::lock_guard<std::mutex> g(g_scratch_mu); g_scratch[dev & 15][slot].p = p; g_scratch[dev & 15][slot].bytes = bytes; }
+        return 0;
+    }
+    void release()
+    {
+        if (slot < 0) return;
+        if (cached) { std::lock_guard<std::mutex> g(g_scratch_mu); g_scratch[dev & 15][slot].busy = false; }
+        else if (p) hipFree(p);
+        p = nullptr; bytes = 0; slot = -1; cached = false;
+    }
+};
+
 extern "C" void mi_release_cache(void)
 {
+    {
+        std::lock_guard<std::mutex> g(g_scratch_mu);
+        for (auto &dv : g_scratch)
+            for (auto &S : dv)
+                if (!S.busy && S.p) { hipFree(S.p); S.p = nullptr; S.bytes = 0; }
+    }
     for (auto &a : g_arena) { if (a.ptr) hipFree(a.ptr); a.ptr = nullptr; a.doubles = 0; }
 }
 
@@ -2038,22 +2088,32 @@ static void plan_runs(int nao, const std::vector<double> &Qblk, double qmax, dou
     const int nblk = (nao + BLK - 1) / BLK, nbp = nblk * (nblk + 1) / 2;
     auto bsize = [&](int B) { return std::min(BLK, nao - B * BLK); };
     plan.clear();
-    for (int kl = 0, K = 0, L = 0; kl < nbp; kl++) {
-        if (Qblk[kl] * qmax >= tol) {
-            const int bk = bsize(K);
-            for (int J = 0; J < nblk; J++) {
-                RunPlan r{J, K, L, 0, 0, 0};
-                for (int I = J; I < nblk; I++) {
-                    int ij = I * (I + 1) / 2 + J;
-                    if (ij < kl || Qblk[ij] * Qblk[kl] < tol) continue;
-                    r.count++;
-                    r.bytes += tile_doubles_padded(tri && I == J, tri && K == L, bsize(I), bk) * 8;
-                }
-                if (r.count) plan.push_back(r);
+    // (13.6 M candidate tiles for ibuprofen/def2-TZVP: the ket block pairs are scanned by the host threads, their run lists
+    // joined in kl order -- the plan does not depend on the number of threads)
+    std::vector<std::vector<RunPlan>> per(nbp);
+#pragma omp parallel for schedule(dynamic, 8) num_threads(host_threads())
+    for (int kl = 0; kl < nbp; kl++) {
+        if (!(Qblk[kl] * qmax >= tol)) continue;
+        int K = (int)((std::sqrt(8.0 * kl + 1.0) - 1.0) / 2.0);
+        while ((K + 1) * (K + 2) / 2 <= kl) K++;
+        while (K * (K + 1) / 2 > kl) K--;
+        const int L = kl - K * (K + 1) / 2;
+        const int bk = bsize(K);
+        for (int J = 0; J < nblk; J++) {
+            RunPlan r{J, K, L, 0, 0, 0};
+            for (int I = J; I < nblk; I++) {
+                int ij = I * (I + 1) / 2 + J;
+                if (ij < kl || Qblk[ij] * Qblk[kl] < tol) continue;
+                r.count++;
+                r.bytes += tile_doubles_padded(tri && I == J, tri && K == L, bsize(I), bk) * 8;
             }
+            if (r.count) per[kl].push_back(r);
         }
-        if (++L > K) { K++; L = 0; }
     }
+    size_t nrun = 0;
+    for (const auto &v : per) nrun += v.size();
+    plan.reserve(nrun);
+    for (const auto &v : per) plan.insert(plan.end(), v.begin(), v.end());
     if (nranks <= 1) return;
     std::vector<int> ord(plan.size());
     std::iota(ord.begin(), ord.end(), 0);
@@ -2185,8 +2245,9 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                 WORK_DOUBLES = (size_t)std::min<double>((double)cap, std::max<double>((double)WORK_DOUBLES, need));
             }
     }
-    double *d_work = nullptr;
-    HIPCHK(hipMalloc(&d_work, sizeof(double) * WORK_DOUBLES));
+    Scratch scr_work, scr_tasks;   // (returned to the per-device cache when this call ends, whichever way)
+    if (scr_work.ensure(c->device, SCR_EVAL_WORK, sizeof(double) * WORK_DOUBLES)) return -1;
+    double *d_work = (double *)scr_work.p;
     uint32_t *d_comp = nullptr;
     HIPCHK(hipMalloc(&d_comp, sizeof(uint32_t) * 8192));
 
@@ -2313,7 +2374,26 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         c->tri = c->opt_tri_tiles != 0;
         plan_runs(c->nao, Qblk, qmax, tol, nranks, c->tri != 0, plan);
         std::vector<uint8_t> present(nranks > 1 ? table.size() : 0, 0); // sharded store: slots that live on SOME rank
-        for (const RunPlan &rp : plan) {
+        // first tile and first double of every run of this rank from the plan's counts / bytes, then the runs are filled by the
+        // host threads (disjoint slices of the tile list, disjoint directory slots)
+        const size_t nplan = plan.size();
+        std::vector<int64_t> first_tile(nplan + 1, 0), first_off(nplan + 1, 0);
+        std::vector<int> run_slot(nplan, -1);
+        int nown = 0;
+        for (size_t q = 0; q < nplan; q++) {
+            const bool mine = plan[q].owner == rank;
+            first_tile[q + 1] = first_tile[q] + (mine ? plan[q].count : 0);
+            first_off[q + 1] = first_off[q] + (mine ? plan[q].bytes / 8 : 0);
+            if (mine) run_slot[q] = nown++;
+        }
+        if (first_tile[nplan] >= INT32_MAX) return fail("too many tiles");
+        c->tiles.resize((size_t)first_tile[nplan]);
+        c->tile_off.resize((size_t)first_tile[nplan]);
+        c->runs.resize((size_t)nown);
+        int bad = 0;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(host_threads()) reduction(+ : nuniq) reduction(| : bad)
+        for (size_t q = 0; q < nplan; q++) {
+            const RunPlan &rp = plan[q];
             const int J = rp.J, K = rp.K, L = rp.L, kl = K * (K + 1) / 2 + L;
             if (rp.owner != rank) {
                 for (int I = J; I < nblk; I++) {
@@ -2322,30 +2402,35 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                 }
                 continue;
             }
-            RunRec cur{J, K, L, (int)c->tiles.size(), 0};
+            int tid = (int)first_tile[q];
+            int64_t o = first_off[q];
+            RunRec cur{J, K, L, tid, 0};
             for (int I = J; I < nblk; I++) {
                 int ij = I * (I + 1) / 2 + J;
                 if (ij < kl) continue;
                 if (Qblk[ij] * Qblk[kl] < tol) continue;
-                table[(size_t)ij * (ij + 1) / 2 + kl] = (int32_t)c->tiles.size();
-                c->tiles.push_back({I, J, K, L});
-                c->tile_off.push_back(off);
+                table[(size_t)ij * (ij + 1) / 2 + kl] = (int32_t)tid;
+                c->tiles[tid] = {I, J, K, L};
+                c->tile_off[tid] = o;
                 int bi = bsize(I), bj = bsize(J), bk = bsize(K), bl = bsize(L);
-                off += tile_doubles_padded(c->tri && I == J, c->tri && K == L, bi, bk); // j is always padded to 8 rows (J==last implies I==last: rare)
+                o += tile_doubles_padded(c->tri && I == J, c->tri && K == L, bi, bk); // j is always padded to 8 rows (J==last implies I==last: rare)
                 int64_t nij = (I > J) ? (int64_t)bi * bj : (int64_t)bi * (bi + 1) / 2;
                 int64_t nkl = (K > L) ? (int64_t)bk * bl : (int64_t)bk * (bk + 1) / 2;
                 nuniq += (ij > kl) ? nij * nkl : nij * (nij + 1) / 2;
-                cur.count++;
+                cur.count++; tid++;
             }
-            if (cur.count != rp.count) return fail("internal: run plan / tile enumeration mismatch");
-            c->runs.push_back(cur);
+            if (cur.count != rp.count || o != first_off[q + 1]) bad |= 1;
+            c->runs[run_slot[q]] = cur;
         }
+        if (bad) return fail("internal: run plan / tile enumeration mismatch");
+        off = first_off[nplan];
         if (c->d_tile_present) { hipFree(c->d_tile_present); c->d_tile_present = nullptr; }
         if (nranks > 1 && upload(&c->d_tile_present, present)) return -1;
     }
     c->n_tiles = (int64_t)c->tiles.size();
     c->tile_doubles = off;
     if (c->n_tiles >= INT32_MAX) return fail("too many tiles");
+    lap("  plan + tile enumeration");
     if (upload(&c->d_tile_table, table)) return -1;
     if (upload(&c->d_tile_off, c->tile_off)) return -1;
     {
@@ -2353,6 +2438,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         for (size_t i = 0; i < tI.size(); i++) tI[i] = c->tiles[i].I;
         if (upload(&c->d_tile_I, tI)) return -1;
         if (upload(&c->d_runs, c->runs)) return -1;
+        lap("  directory uploads");
         // J/K work items ("segments"): runs cut into chunks; either one wave per item (longest first, the
         // hardware dispatcher balances) or a fixed number of waves with equal-cost contiguous shares.
         auto tile_cost = [&](int tid) {
@@ -2367,6 +2453,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             for (const RunRec &r : c->runs)
                 for (int t0 = 0; t0 < r.count; t0 += chunk) segs.push_back(RunRec{r.J, r.K, r.L, r.first + t0, std::min(chunk, r.count - t0)});
             std::vector<double> cost(segs.size(), 0.0);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
             for (size_t q = 0; q < segs.size(); q++)
                 for (int t = 0; t < segs[q].count; t++) cost[q] += tile_cost(segs[q].first + t);
             std::vector<int> ord(segs.size());
@@ -2380,6 +2467,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                 double acc_b = 0.0;
                 const double lim = (double)c->opt_jk_cache_mb * 1048576.0;
                 std::vector<double> sc(segs.size(), 0.0);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
                 for (size_t q = 0; q < segs.size(); q++)
                     for (int t = 0; t < segs[q].count; t++) sc[q] += tile_cost(segs[q].first + t) - 8192.0;
                 while (c->n_jk_cached < (int)segs.size() && acc_b + sc[c->n_jk_cached] <= lim) acc_b += sc[c->n_jk_cached++];
@@ -2427,13 +2515,14 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         if (upload(&c->d_segs, segs)) return -1;
         if (upload(&c->d_wave_seg, wave_seg)) return -1;
     }
+    lap("  J/K segments");
     size_t freeb = 0, totb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totb));
     freeb += (size_t)g_arena[c->device & 15].doubles * 8; // a parked store is reusable (or freed) by arena_take
     c->mem_need_bytes = (int64_t)off * 8;
     c->mem_free_bytes = (int64_t)freeb;
     if ((size_t)off * 8 + ((size_t)1 << 30) > freeb) {
-        hipFree(d_work); hipFree(d_comp);
+        hipFree(d_comp);
         fail("resident ERI store needs %.1f GB but only %.1f GB of HBM is free; shard over more GPUs",
              off * 8e-9, freeb * 1e-9);
         return MI_ERR_NOMEM; // sizes: mi_eri_get_memory
@@ -2480,9 +2569,9 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
                                    tpq_has_class(B.la, B.lb, Kc.la, Kc.lb);
             if (c->opt_task_table && !tpq_class && ntask >= 65536) {   // the wave-per-quartet pair walks the task list twice
                 if ((size_t)ntask > tasks_cap) {
-                    if (d_tasks) hipFree(d_tasks);
-                    tasks_cap = (size_t)ntask + (size_t)ntask / 4;
-                    HIPCHK(hipMalloc(&d_tasks, sizeof(TaskIdx) * tasks_cap));
+                    if (scr_tasks.ensure(c->device, SCR_EVAL_TASKS, sizeof(TaskIdx) * (size_t)ntask)) return -1;
+                    d_tasks = (TaskIdx *)scr_tasks.p;
+                    tasks_cap = scr_tasks.bytes / sizeof(TaskIdx);
                 }
                 hipLaunchKernelGGL(fill_tasks_kernel, dim3((unsigned)((ntask + 255) / 256)), dim3(256), 0, st, d_prefix, (int)B.recs.size(), ntask, d_tasks);
                 E.tasks = d_tasks;
@@ -2612,9 +2701,8 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     HIPCHK(hipStreamSynchronize(st));
     lap("quartet evaluation");
     if (d_prefix) hipFree(d_prefix);
-    if (d_tasks) hipFree(d_tasks);
-    hipFree(d_work);
     hipFree(d_comp);
+    scr_work.release(); scr_tasks.release();
     lap("free scratch");
     c->stats.n_tiles = c->n_tiles;
     c->stats.n_runs = (int64_t)c->runs.size();
@@ -6099,9 +6187,9 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 WORK_DOUBLES = (size_t)std::min<double>((double)cap, std::max<double>((double)WORK_DOUBLES, need));
             }
     }
-    double *d_wp = nullptr, *d_wm = nullptr;
-    HIPCHK(hipMalloc(&d_wp, sizeof(double) * WORK_DOUBLES));
-    HIPCHK(hipMalloc(&d_wm, sizeof(double) * WORK_DOUBLES));
+    Scratch scr_wp, scr_wm, scr_gtasks, scr_live;
+    if (scr_wp.ensure(c->device, SCR_GRAD_WP, sizeof(double) * WORK_DOUBLES) || scr_wm.ensure(c->device, SCR_GRAD_WM, sizeof(double) * WORK_DOUBLES)) return -1;
+    double *d_wp = (double *)scr_wp.p, *d_wm = (double *)scr_wm.p;
     uint32_t *d_comp_p = nullptr, *d_comp_m = nullptr;
     HIPCHK(hipMalloc(&d_comp_p, sizeof(uint32_t) * 16384));
     HIPCHK(hipMalloc(&d_comp_m, sizeof(uint32_t) * 16384));
@@ -6130,9 +6218,9 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
             const bool live_ok = d_dmax && c->opt_grad_live && ntask >= 4096 && ntask <= ((int64_t)1 << 28);   // see ensure_live below
             if (c->opt_task_table && ntask >= 65536 && ntask <= ((int64_t)1 << 28) && !live_ok) {   // up to 3 permutations x 3 launches walk this task list
                 if ((size_t)ntask > tasks_cap) {
-                    if (d_tasks) hipFree(d_tasks);
-                    tasks_cap = (size_t)ntask + (size_t)ntask / 4;
-                    HIPCHK(hipMalloc(&d_tasks, sizeof(TaskIdx) * tasks_cap));
+                    if (scr_gtasks.ensure(c->device, SCR_GRAD_TASKS, sizeof(TaskIdx) * (size_t)ntask)) return -1;
+                    d_tasks = (TaskIdx *)scr_gtasks.p;
+                    tasks_cap = scr_gtasks.bytes / sizeof(TaskIdx);
                 }
                 hipLaunchKernelGGL(fill_tasks_kernel, dim3((unsigned)((ntask + 255) / 256)), dim3(256), 0, st, d_prefix, (int)B.recs.size(), ntask, d_tasks);
                 tasks_dev = d_tasks;
@@ -6153,9 +6241,9 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                     HIPCHK(hipMalloc(&d_live_off, sizeof(int64_t) * live_cap));
                 }
                 if ((size_t)ntask > live_tasks_cap) {
-                    if (d_live_tasks) hipFree(d_live_tasks);
-                    live_tasks_cap = (size_t)ntask + (size_t)ntask / 4;
-                    HIPCHK(hipMalloc(&d_live_tasks, sizeof(TaskIdx) * live_tasks_cap));
+                    if (scr_live.ensure(c->device, SCR_GRAD_LIVE, sizeof(TaskIdx) * (size_t)ntask)) return -1;
+                    d_live_tasks = (TaskIdx *)scr_live.p;
+                    live_tasks_cap = scr_live.bytes / sizeof(TaskIdx);
                 }
                 LiveArgs L{B.d_recs, Kc.d_recs, d_prefix, (int)B.recs.size(), ntask, B.d_q, Kc.d_q, d_dmax, c->nbas, hyb, c->opt_grad_dtol};
                 hipLaunchKernelGGL(live_count_kernel, dim3(nblk), dim3(256), 0, st, L, d_live_counts);
@@ -6335,11 +6423,9 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 std::chrono::duration<double>(tg1 - tg0).count(),
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count());
     if (d_prefix) hipFree(d_prefix);
-    if (d_tasks) hipFree(d_tasks);
-    if (d_live_tasks) hipFree(d_live_tasks);
     if (d_live_counts) hipFree(d_live_counts);
     if (d_live_off) hipFree(d_live_off);
-    hipFree(d_wp); hipFree(d_wm); hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_shell_atom);
+    hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_shell_atom);   // (the Scratch handles go back to the per-device cache)
     if (d_dmax) hipFree(d_dmax);
     if (d_Mpad) hipFree(d_Mpad);
     if (d_sh_ao) hipFree(d_sh_ao);
