@@ -22,6 +22,8 @@
 #include <string>
 #include <thread>
 #include <mutex>
+#include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mi355scf.h"
@@ -52,6 +54,86 @@ static int fail(const char *fmt, ...)
     } while (0)
 
 extern "C" const char *mi_last_error(void) { return g_err.c_str(); }
+
+// -------------------------------------------------------------------------------------------------
+// Device-memory pool for the MANY small and medium buffers of a context (pair records, matrices, directories, per-call
+// scratch): a geometry step creates and destroys ~150 of them, and every hipMalloc / hipFree maps or unmaps pages and
+// synchronises the device (38 ms for the mi_ctx_destroy of ibuprofen/def2-TZVP alone).  dev_free parks a block in a per-device
+// free list by size class (device-synchronised first, like hipFree, so a parked block is never still being read), dev_malloc
+// takes one from there.  Blocks above 1 GiB, the tile store (TileArena) and the hand-over buffers (Scratch) bypass the pool.
+// At most POOL_CAP bytes are parked per device; mi_release_cache and an out-of-memory hipMalloc empty the pool.
+// -------------------------------------------------------------------------------------------------
+static const size_t POOL_CAP = (size_t)6 << 30, POOL_MAX_BLOCK = (size_t)1 << 30;
+struct DevPool {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> live;                  // pooled blocks handed out: pointer -> size class
+    std::map<size_t, std::vector<void *>> parked;             // size class -> free blocks
+    size_t parked_bytes = 0;
+};
+static DevPool g_pool[16];
+static size_t pool_class(size_t n)
+{
+    if (n <= 256) return 256;
+    size_t c = 256;
+    while (c < n) c <<= 1;
+    const size_t three_q = c / 4 * 3;                          // classes 2^k and 3 * 2^(k-2): at most 33 % of slack
+    return (n <= three_q && three_q >= 256) ? three_q : c;
+}
+static void pool_flush(int dev)
+{
+    DevPool &P = g_pool[dev & 15];
+    for (auto &kv : P.parked)
+        for (void *q : kv.second) hipFree(q);
+    P.parked.clear();
+    P.parked_bytes = 0;
+}
+static hipError_t dev_malloc_impl(void **out, size_t n)
+{
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (n > POOL_MAX_BLOCK) return hipMalloc(out, n);
+    DevPool &P = g_pool[dev & 15];
+    const size_t cls = pool_class(std::max<size_t>(n, 1));
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.parked.find(cls);
+    if (it != P.parked.end() && !it->second.empty()) {
+        *out = it->second.back();
+        it->second.pop_back();
+        P.parked_bytes -= cls;
+        P.live[*out] = cls;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, cls);
+    if (e != hipSuccess) {                                    // out of memory: give the parked blocks back and try again
+        (void)hipGetLastError();
+        pool_flush(dev);
+        e = hipMalloc(out, cls);
+    }
+    if (e == hipSuccess) P.live[*out] = cls;
+    return e;
+}
+template <class T> static hipError_t dev_malloc(T **out, size_t n) { return dev_malloc_impl((void **)out, n); }
+static hipError_t dev_free(void *q)
+{
+    if (!q) return hipSuccess;
+    int dev = 0;
+    hipGetDevice(&dev);
+    DevPool &P = g_pool[dev & 15];
+    size_t cls = 0;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.live.find(q);
+        if (it != P.live.end()) { cls = it->second; P.live.erase(it); }
+    }
+    if (!cls) return hipFree(q);                               // not one of ours (large block, or allocated on another device)
+    hipDeviceSynchronize();                                   // what hipFree would have done: nobody reads the block any more
+    std::lock_guard<std::mutex> g(P.mu);
+    if (P.parked_bytes + cls > POOL_CAP) return hipFree(q);
+    P.parked[cls].push_back(q);
+    P.parked_bytes += cls;
+    return hipSuccess;
+}
+static size_t pool_parked_bytes(int dev) { DevPool &P = g_pool[dev & 15]; std::lock_guard<std::mutex> g(P.mu); return P.parked_bytes; }
 
 // Host-side OpenMP is used only for the per-pair transformation matrices.  Idle workers must not spin
 // (libomp's default 200 ms block time starves the Python/torch threads between calls).
@@ -397,6 +479,14 @@ static int set_tile_order(mi_ctx *c, int order)
     return 0;
 }
 
+struct HostStash {
+    std::mutex mu;
+    std::vector<double> h_M, h_prim;
+    std::vector<TileInfo> tiles;
+    std::vector<int64_t> tile_off;
+};
+static HostStash g_stash[16];
+
 extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, int nbas, const double *env,
                              int nenv, int device_id, mi_ctx **out)
 {
@@ -433,19 +523,19 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
     c->npad = c->nblk * BLK;
     c->ldp = c->npad + BLK;
     // device copies
-    HIPCHK(hipMalloc(&c->d_env, sizeof(double) * nenv));
+    HIPCHK(dev_malloc(&c->d_env, sizeof(double) * nenv));
     HIPCHK(hipMemcpy(c->d_env, env, sizeof(double) * nenv, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&c->d_bas, sizeof(int32_t) * nbas * BAS_SLOTS));
+    HIPCHK(dev_malloc(&c->d_bas, sizeof(int32_t) * nbas * BAS_SLOTS));
     HIPCHK(hipMemcpy(c->d_bas, bas, sizeof(int32_t) * nbas * BAS_SLOTS, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&c->d_atm, sizeof(int32_t) * natm * ATM_SLOTS));
+    HIPCHK(dev_malloc(&c->d_atm, sizeof(int32_t) * natm * ATM_SLOTS));
     HIPCHK(hipMemcpy(c->d_atm, atm, sizeof(int32_t) * natm * ATM_SLOTS, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&c->d_shell_ao, sizeof(int) * (nbas + 1)));
+    HIPCHK(dev_malloc(&c->d_shell_ao, sizeof(int) * (nbas + 1)));
     HIPCHK(hipMemcpy(c->d_shell_ao, shell_ao.data(), sizeof(int) * (nbas + 1), hipMemcpyHostToDevice));
     {
         std::vector<double> xyz((size_t)nbas * 3);
         for (int i = 0; i < nbas; i++)
             for (int d = 0; d < 3; d++) xyz[3 * i + d] = c->shells[i].r[d];
-        HIPCHK(hipMalloc(&c->d_shell_xyz, sizeof(double) * xyz.size()));
+        HIPCHK(dev_malloc(&c->d_shell_xyz, sizeof(double) * xyz.size()));
         HIPCHK(hipMemcpy(c->d_shell_xyz, xyz.data(), sizeof(double) * xyz.size(), hipMemcpyHostToDevice));
     }
     // c2s tables
@@ -457,14 +547,14 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
         all.insert(all.end(), t.begin(), t.end());
     }
     c->c2s_off[LMAX + 1] = (int)all.size();
-    HIPCHK(hipMalloc(&c->d_c2s, sizeof(double) * all.size()));
+    HIPCHK(dev_malloc(&c->d_c2s, sizeof(double) * all.size()));
     HIPCHK(hipMemcpy(c->d_c2s, all.data(), sizeof(double) * all.size(), hipMemcpyHostToDevice));
     // Rys tables
-    HIPCHK(hipMalloc(&c->d_rys_cheb, sizeof(double) * RYS_CHEB_SIZE));
+    HIPCHK(dev_malloc(&c->d_rys_cheb, sizeof(double) * RYS_CHEB_SIZE));
     HIPCHK(hipMemcpy(c->d_rys_cheb, RYS_CHEB_H, sizeof(double) * RYS_CHEB_SIZE, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&c->d_herm_r, sizeof(RYS_HERM_R_H)));
+    HIPCHK(dev_malloc(&c->d_herm_r, sizeof(RYS_HERM_R_H)));
     HIPCHK(hipMemcpy(c->d_herm_r, RYS_HERM_R_H, sizeof(RYS_HERM_R_H), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&c->d_herm_w, sizeof(RYS_HERM_W_H)));
+    HIPCHK(dev_malloc(&c->d_herm_w, sizeof(RYS_HERM_W_H)));
     HIPCHK(hipMemcpy(c->d_herm_w, RYS_HERM_W_H, sizeof(RYS_HERM_W_H), hipMemcpyHostToDevice));
     c->rys.cheb = c->d_rys_cheb; c->rys.herm_r = c->d_herm_r; c->rys.herm_w = c->d_herm_w;
     for (int i = 0; i <= RYS_NMAX + 1; i++) c->rys.off[i] = RYS_OFFSET_H[i];
@@ -474,14 +564,20 @@ extern "C" int mi_ctx_create(const int32_t *atm, int natm, const int32_t *bas, i
     // J/K buffers
     size_t pp = (size_t)c->ldp * c->ldp;
     // two of each: the spin pair of UHF / UKS is digested by one launch (jk_tiles_pair_kernel)
-    HIPCHK(hipMalloc(&c->d_Dpad, sizeof(double) * 2 * pp));
-    HIPCHK(hipMalloc(&c->d_Jacc, sizeof(double) * 2 * pp));
-    HIPCHK(hipMalloc(&c->d_Kacc, sizeof(double) * 2 * pp));
-    HIPCHK(hipMalloc(&c->d_red, sizeof(double) * 4096));
-    HIPCHK(hipMalloc(&c->d_perm, sizeof(int) * std::max(ao, 1)));
-    HIPCHK(hipMalloc(&c->d_iperm, sizeof(int) * std::max(ao, 1)));
+    HIPCHK(dev_malloc(&c->d_Dpad, sizeof(double) * 2 * pp));
+    HIPCHK(dev_malloc(&c->d_Jacc, sizeof(double) * 2 * pp));
+    HIPCHK(dev_malloc(&c->d_Kacc, sizeof(double) * 2 * pp));
+    HIPCHK(dev_malloc(&c->d_red, sizeof(double) * 4096));
+    HIPCHK(dev_malloc(&c->d_perm, sizeof(int) * std::max(ao, 1)));
+    HIPCHK(dev_malloc(&c->d_iperm, sizeof(int) * std::max(ao, 1)));
     c->ao_order = -1;
     if (set_tile_order(c, 0)) { return -1; }
+    {   // large host vectors left behind by the previous context of this device (mi_ctx_destroy): capacity without page faults
+        HostStash &H = g_stash[c->device & 15];
+        std::lock_guard<std::mutex> g(H.mu);
+        H.h_M.clear(); H.h_prim.clear(); H.tiles.clear(); H.tile_off.clear();
+        c->h_M.swap(H.h_M); c->h_prim.swap(H.h_prim); c->tiles.swap(H.tiles); c->tile_off.swap(H.tile_off);
+    }
     *out = c;
     return 0;
 }
@@ -500,7 +596,11 @@ static int arena_take(int dev, int64_t need, double **out)
         return 0;
     }
     if (a.ptr) { hipFree(a.ptr); a.ptr = nullptr; a.doubles = 0; }
-    HIPCHK(hipMalloc((void **)out, sizeof(double) * need));
+    if (hipMalloc((void **)out, sizeof(double) * need) != hipSuccess) {   // the pool's parked blocks may be what is missing
+        (void)hipGetLastError();
+        { std::lock_guard<std::mutex> g(g_pool[dev & 15].mu); pool_flush(dev); }
+        HIPCHK(hipMalloc((void **)out, sizeof(double) * need));
+    }
     g_arena_alloc_bytes.push_back((int64_t)sizeof(double) * need);
     return 0;
 }
@@ -572,6 +672,7 @@ extern "C" void mi_release_cache(void)
                 if (!S.busy && S.p) { hipFree(S.p); S.p = nullptr; S.bytes = 0; }
     }
     for (auto &a : g_arena) { if (a.ptr) hipFree(a.ptr); a.ptr = nullptr; a.doubles = 0; }
+    for (int d = 0; d < 16; d++) { std::lock_guard<std::mutex> g(g_pool[d].mu); if (g_pool[d].parked_bytes) { hipSetDevice(d); pool_flush(d); } }
 }
 
 static void free_eri(mi_ctx *c)
@@ -580,12 +681,12 @@ static void free_eri(mi_ctx *c)
     c->grad_host_ready = false;
     if (c->d_tiles) { arena_give(c->device, c->d_tiles, c->tile_alloc); c->d_tiles = nullptr; }
     for (int i = 0; i < NPC; i++) {
-        if (c->pc[i].d_recs) hipFree(c->pc[i].d_recs);
-        if (c->pc[i].d_q) hipFree(c->pc[i].d_q);
+        if (c->pc[i].d_recs) dev_free(c->pc[i].d_recs);
+        if (c->pc[i].d_q) dev_free(c->pc[i].d_q);
         c->pc[i].d_recs = nullptr; c->pc[i].d_q = nullptr;
         for (int o = 0; o < 2; o++)
             for (int sg = 0; sg < 2; sg++) {
-                if (c->pc[i].d_g_recs[o][sg]) hipFree(c->pc[i].d_g_recs[o][sg]);
+                if (c->pc[i].d_g_recs[o][sg]) dev_free(c->pc[i].d_g_recs[o][sg]);
                 c->pc[i].d_g_recs[o][sg] = nullptr;
                 c->pc[i].g_recs[o][sg].clear();
             }
@@ -593,7 +694,7 @@ static void free_eri(mi_ctx *c)
     }
     void *ptrs[] = {c->d_prim, c->d_M, c->d_tile_table, c->d_tile_off, c->d_tile_I, c->d_runs, c->d_tiles, c->d_segs, c->d_wave_seg,
                     c->d_tile_present};
-    for (void *p : ptrs) if (p) hipFree(p);
+    for (void *p : ptrs) if (p) dev_free(p);
     c->d_tile_present = nullptr;
     c->d_prim = c->d_M = nullptr; c->d_tile_table = nullptr; c->d_tile_off = nullptr; c->d_tile_I = nullptr;
     c->d_runs = nullptr; c->d_tiles = nullptr; c->d_segs = nullptr; c->d_wave_seg = nullptr;
@@ -617,7 +718,18 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     free_eri(c);
     void *ptrs[] = {c->d_env, c->d_bas, c->d_atm, c->d_shell_ao, c->d_c2s, c->d_rys_cheb, c->d_herm_r, c->d_herm_w,
                     c->d_Dpad, c->d_Jacc, c->d_Kacc, c->d_red, c->d_shell_xyz, c->d_sp2_bar, c->d_xt_scratch, c->d_perm, c->d_iperm};
-    for (void *p : ptrs) if (p) hipFree(p);
+    for (void *p : ptrs) if (p) dev_free(p);
+    // the large host vectors of the context (pair records and gradient matrices, tile directory: several hundred MB for
+    // ibuprofen/def2-TZVP) are handed to the next context on this device instead of being unmapped here (~40 ms) and faulted
+    // in again there: a geometry step replaces its context
+    {
+        HostStash &H = g_stash[c->device & 15];
+        std::lock_guard<std::mutex> g(H.mu);
+        if (c->h_M.capacity() > H.h_M.capacity()) H.h_M.swap(c->h_M);
+        if (c->h_prim.capacity() > H.h_prim.capacity()) H.h_prim.swap(c->h_prim);
+        if (c->tiles.capacity() > H.tiles.capacity()) H.tiles.swap(c->tiles);
+        if (c->tile_off.capacity() > H.tile_off.capacity()) H.tile_off.swap(c->tile_off);
+    }
     delete c;
 }
 
@@ -1961,9 +2073,9 @@ static int64_t class_prefix(const PairClass &B, const PairClass &Kc, bool same, 
 template <class T>
 static int upload(T **dst, const std::vector<T> &v)
 {
-    if (*dst) { hipFree(*dst); *dst = nullptr; }
+    if (*dst) { dev_free(*dst); *dst = nullptr; }
     size_t n = std::max<size_t>(v.size(), 1);
-    HIPCHK(hipMalloc((void **)dst, sizeof(T) * n));
+    HIPCHK(dev_malloc_impl((void **)dst, sizeof(T) * n));
     if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
     return 0;
 }
@@ -2249,7 +2361,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     if (scr_work.ensure(c->device, SCR_EVAL_WORK, sizeof(double) * WORK_DOUBLES)) return -1;
     double *d_work = (double *)scr_work.p;
     uint32_t *d_comp = nullptr;
-    HIPCHK(hipMalloc(&d_comp, sizeof(uint32_t) * 8192));
+    HIPCHK(dev_malloc(&d_comp, sizeof(uint32_t) * 8192));
 
     // ---- 2. Schwarz bounds per pair (GPU)
     double qmax = 0.0;
@@ -2258,7 +2370,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         if (P.recs.empty()) continue;
         if (upload(&P.d_recs, P.recs)) return -1;
         P.q.assign(P.recs.size(), 0.0);
-        HIPCHK(hipMalloc(&P.d_q, sizeof(double) * P.recs.size()));
+        HIPCHK(dev_malloc(&P.d_q, sizeof(double) * P.recs.size()));
         EriArgs E{};
         setup_eri_dims(E, P.la, P.lb, P.la, P.lb);
         std::vector<uint32_t> comp;
@@ -2424,7 +2536,7 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         }
         if (bad) return fail("internal: run plan / tile enumeration mismatch");
         off = first_off[nplan];
-        if (c->d_tile_present) { hipFree(c->d_tile_present); c->d_tile_present = nullptr; }
+        if (c->d_tile_present) { dev_free(c->d_tile_present); c->d_tile_present = nullptr; }
         if (nranks > 1 && upload(&c->d_tile_present, present)) return -1;
     }
     c->n_tiles = (int64_t)c->tiles.size();
@@ -2519,10 +2631,11 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
     size_t freeb = 0, totb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totb));
     freeb += (size_t)g_arena[c->device & 15].doubles * 8; // a parked store is reusable (or freed) by arena_take
+    freeb += pool_parked_bytes(c->device);                // ... and so are the pool's parked blocks
     c->mem_need_bytes = (int64_t)off * 8;
     c->mem_free_bytes = (int64_t)freeb;
     if ((size_t)off * 8 + ((size_t)1 << 30) > freeb) {
-        hipFree(d_comp);
+        dev_free(d_comp);
         fail("resident ERI store needs %.1f GB but only %.1f GB of HBM is free; shard over more GPUs",
              off * 8e-9, freeb * 1e-9);
         return MI_ERR_NOMEM; // sizes: mi_eri_get_memory
@@ -2558,9 +2671,9 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
             if (ntask == 0) continue;
             nquart += ntask;
             if (prefix.size() > prefix_cap) {
-                if (d_prefix) hipFree(d_prefix);
+                if (d_prefix) dev_free(d_prefix);
                 prefix_cap = prefix.size() * 2;
-                HIPCHK(hipMalloc(&d_prefix, sizeof(int64_t) * prefix_cap));
+                HIPCHK(dev_malloc(&d_prefix, sizeof(int64_t) * prefix_cap));
             }
             HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
             EriArgs E{};
@@ -2700,8 +2813,8 @@ extern "C" int mi_eri_prepare(mi_ctx *c, double tol, int rank, int nranks, void 
         }
     HIPCHK(hipStreamSynchronize(st));
     lap("quartet evaluation");
-    if (d_prefix) hipFree(d_prefix);
-    hipFree(d_comp);
+    if (d_prefix) dev_free(d_prefix);
+    dev_free(d_comp);
     scr_work.release(); scr_tasks.release();
     lap("free scratch");
     c->stats.n_tiles = c->n_tiles;
@@ -2830,8 +2943,8 @@ extern "C" int mi_df_build(mi_ctx *c, mi_ctx *aux, double *d_int3c, double *d_in
     for (int q = 0; q < NPC; q++) if (!D.recs[q].empty() && upload(&d_rec_o[q], D.recs[q])) return -1;
     for (int l = 0; l <= LMAX; l++) if (!D.aux[l].empty() && upload(&d_rec_a[l], D.aux[l])) return -1;
     const size_t WORK_DOUBLES = (size_t)32 << 20;
-    HIPCHK(hipMalloc(&d_work, sizeof(double) * WORK_DOUBLES));
-    HIPCHK(hipMalloc(&d_comp, sizeof(uint32_t) * 8192));
+    HIPCHK(dev_malloc(&d_work, sizeof(double) * WORK_DOUBLES));
+    HIPCHK(dev_malloc(&d_comp, sizeof(uint32_t) * 8192));
     size_t prefix_cap = 0;
     // one pass per (bra class, auxiliary l): bra = orbital pairs (3-index) or auxiliary pairs (2-index)
     auto run = [&](const PairRec *d_bra, int nbra, int la, int lb, int lk, int mode, double *out, int ld_nao) -> int {
@@ -2842,9 +2955,9 @@ extern "C" int mi_df_build(mi_ctx *c, mi_ctx *aux, double *d_int3c, double *d_in
         const int64_t ntask = prefix.back();
         append_coarse_index(prefix);
         if (prefix.size() > prefix_cap) {
-            if (d_prefix) hipFree(d_prefix);
+            if (d_prefix) dev_free(d_prefix);
             prefix_cap = prefix.size() * 2;
-            HIPCHK(hipMalloc(&d_prefix, sizeof(int64_t) * prefix_cap));
+            HIPCHK(dev_malloc(&d_prefix, sizeof(int64_t) * prefix_cap));
         }
         HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
         EriArgs E{};
@@ -2885,10 +2998,10 @@ extern "C" int mi_df_build(mi_ctx *c, mi_ctx *aux, double *d_int3c, double *d_in
     if (d_int2c)
         for (int lp = 0; lp <= LMAX && !rc; lp++)
             for (int lk = 0; lk <= LMAX && !rc; lk++) rc = run(d_rec_a[lp], (int)D.aux[lp].size(), lp, 0, lk, 2, d_int2c, naux);
-    for (int q = 0; q < NPC; q++) if (d_rec_o[q]) hipFree(d_rec_o[q]);
-    for (int l = 0; l <= LMAX; l++) if (d_rec_a[l]) hipFree(d_rec_a[l]);
-    hipFree(d_prim); hipFree(d_M); hipFree(d_work); hipFree(d_comp);
-    if (d_prefix) hipFree(d_prefix);
+    for (int q = 0; q < NPC; q++) if (d_rec_o[q]) dev_free(d_rec_o[q]);
+    for (int l = 0; l <= LMAX; l++) if (d_rec_a[l]) dev_free(d_rec_a[l]);
+    dev_free(d_prim); dev_free(d_M); dev_free(d_work); dev_free(d_comp);
+    if (d_prefix) dev_free(d_prefix);
     return rc;
 }
 
@@ -3395,7 +3508,7 @@ extern "C" int mi_eri_unpack(mi_ctx *c, double *d_out, void *stream)
     hipLaunchKernelGGL(eri_unpack_kernel, dim3((unsigned)c->n_tiles), dim3(256), 0, st, c->d_tiles, c->d_tile_off, d_info, c->nao, c->tri, d_out, c->d_iperm);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    hipFree(d_info);
+    dev_free(d_info);
     return 0;
 }
 
@@ -3436,12 +3549,12 @@ extern "C" int mi_eri_read_quartet(mi_ctx *c, int ish, int jsh, int ksh, int lsh
     for (int q = 0; q < 4; q++) { ao[q] = c->shells[sh[q]].ao; n[q] = 2 * c->shells[sh[q]].l + 1; }
     const int tot = n[0] * n[1] * n[2] * n[3];
     double *d_out = nullptr;
-    HIPCHK(hipMalloc(&d_out, sizeof(double) * tot));
+    HIPCHK(dev_malloc(&d_out, sizeof(double) * tot));
     hipLaunchKernelGGL(eri_read_quartet_kernel, dim3((tot + 255) / 256), dim3(256), 0, nullptr, c->d_tiles, c->d_tile_off, c->d_tile_table,
                        c->nao, ao[0], n[0], ao[1], n[1], ao[2], n[2], ao[3], n[3], c->d_tile_present, c->tri, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, d_out, sizeof(double) * tot, hipMemcpyDeviceToHost));
-    hipFree(d_out);
+    dev_free(d_out);
     return 0;
 }
 
@@ -3853,14 +3966,14 @@ extern "C" int mi_grid_becke(mi_ctx *c, const double *d_coords, const int32_t *d
     for (int i = 0; i < c->natm; i++)
         for (int d = 0; d < 3; d++) xyz[3 * i + d] = c->env[c->atm[i * ATM_SLOTS + 1] + d];
     double *d_xyz = nullptr;
-    HIPCHK(hipMalloc(&d_xyz, sizeof(double) * xyz.size()));
+    HIPCHK(dev_malloc(&d_xyz, sizeof(double) * xyz.size()));
     HIPCHK(hipMemcpy(d_xyz, xyz.data(), sizeof(double) * xyz.size(), hipMemcpyHostToDevice));
     BeckeArgs A{d_coords, d_atom_of, d_vol, d_xyz, d_adjust, c->natm, ng, d_weights};
     hipLaunchKernelGGL(becke_weights_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), sizeof(double) * 3 * c->natm,
                        (hipStream_t)stream, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    hipFree(d_xyz);
+    dev_free(d_xyz);
     return 0;
 }
 
@@ -4133,7 +4246,7 @@ extern "C" int mi_xc_tail(mi_ctx *c, const double *d_w, const double *d_v0, cons
     if (!c || !d_w || !d_v0 || !d_tail || ng < 1) return fail("mi_xc_tail: bad argument");
     if (!c->d_xt_scratch) {
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipMalloc(&c->d_xt_scratch, sizeof(double) * (XT_MAXWG * 3 + 1)));
+        HIPCHK(dev_malloc(&c->d_xt_scratch, sizeof(double) * (XT_MAXWG * 3 + 1)));
         HIPCHK(hipMemsetAsync(c->d_xt_scratch, 0, sizeof(double) * (XT_MAXWG * 3 + 1), (hipStream_t)stream));
     }
     XcTailArgs A{};
@@ -6153,7 +6266,7 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
     hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_D, c->d_Dpad, c->nao, c->ldp, c->d_iperm);
     double *d_Mpad = nullptr; // spin density Da - Db, padded like D (open shell only)
     if (d_Dspin) {
-        HIPCHK(hipMalloc(&d_Mpad, sizeof(double) * pp));
+        HIPCHK(dev_malloc(&d_Mpad, sizeof(double) * pp));
         hipLaunchKernelGGL(pad_density_kernel, dim3((unsigned)((pp + 255) / 256)), dim3(256), 0, st, d_Dspin, d_Mpad, c->nao, c->ldp, c->d_iperm);
     }
     std::vector<int> shell_atom(c->nbas);
@@ -6167,14 +6280,14 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
         std::vector<int> sh_ao(c->nbas), sh_n(c->nbas);
         for (int i = 0; i < c->nbas; i++) { sh_ao[i] = c->shells[i].ao; sh_n[i] = 2 * c->shells[i].l + 1; }
         if (upload(&d_sh_ao, sh_ao) || upload(&d_sh_n, sh_n)) return -1;
-        HIPCHK(hipMalloc(&d_dmax, sizeof(double) * (size_t)c->nbas * c->nbas));
+        HIPCHK(dev_malloc(&d_dmax, sizeof(double) * (size_t)c->nbas * c->nbas));
         hipLaunchKernelGGL(shell_dmax_kernel, dim3((c->nbas * c->nbas + 255) / 256), dim3(256), 0, st, c->d_Dpad, d_Mpad, c->ldp, d_sh_ao, d_sh_n,
                            c->nbas, d_dmax);
         HIPCHK(hipGetLastError());
     }
     const int natm3 = c->natm * 3;
     double *d_gcopies = nullptr;
-    HIPCHK(hipMalloc(&d_gcopies, sizeof(double) * (size_t)GRAD_COPIES * natm3));
+    HIPCHK(dev_malloc(&d_gcopies, sizeof(double) * (size_t)GRAD_COPIES * natm3));
     HIPCHK(hipMemsetAsync(d_gcopies, 0, sizeof(double) * (size_t)GRAD_COPIES * natm3, st));
     size_t WORK_DOUBLES = (size_t)8 << 17; // per buffer (plus / minus): what the molecule can need, at most `grad_work_mb`
     {
@@ -6191,8 +6304,8 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
     if (scr_wp.ensure(c->device, SCR_GRAD_WP, sizeof(double) * WORK_DOUBLES) || scr_wm.ensure(c->device, SCR_GRAD_WM, sizeof(double) * WORK_DOUBLES)) return -1;
     double *d_wp = (double *)scr_wp.p, *d_wm = (double *)scr_wm.p;
     uint32_t *d_comp_p = nullptr, *d_comp_m = nullptr;
-    HIPCHK(hipMalloc(&d_comp_p, sizeof(uint32_t) * 16384));
-    HIPCHK(hipMalloc(&d_comp_m, sizeof(uint32_t) * 16384));
+    HIPCHK(dev_malloc(&d_comp_p, sizeof(uint32_t) * 16384));
+    HIPCHK(dev_malloc(&d_comp_m, sizeof(uint32_t) * 16384));
     int64_t *d_prefix = nullptr;
     size_t prefix_cap = 0;
     TaskIdx *d_tasks = nullptr, *d_live_tasks = nullptr;
@@ -6209,9 +6322,9 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
             const int64_t ntask = class_prefix(B, Kc, bc == kc, tol, prefix);
             if (ntask == 0) continue;
             if (prefix.size() > prefix_cap) {
-                if (d_prefix) hipFree(d_prefix);
+                if (d_prefix) dev_free(d_prefix);
                 prefix_cap = prefix.size() * 2;
-                HIPCHK(hipMalloc(&d_prefix, sizeof(int64_t) * prefix_cap));
+                HIPCHK(dev_malloc(&d_prefix, sizeof(int64_t) * prefix_cap));
             }
             HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
             const TaskIdx *tasks_dev = nullptr;
@@ -6234,11 +6347,11 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
                 if (nlive >= 0 || !live_ok) return 0;
                 const int nblk = (int)((ntask + 255) / 256);
                 if ((size_t)nblk + 1 > live_cap) {
-                    if (d_live_counts) hipFree(d_live_counts);
-                    if (d_live_off) hipFree(d_live_off);
+                    if (d_live_counts) dev_free(d_live_counts);
+                    if (d_live_off) dev_free(d_live_off);
                     live_cap = (size_t)nblk + 1 + (size_t)nblk / 4;
-                    HIPCHK(hipMalloc(&d_live_counts, sizeof(int) * live_cap));
-                    HIPCHK(hipMalloc(&d_live_off, sizeof(int64_t) * live_cap));
+                    HIPCHK(dev_malloc(&d_live_counts, sizeof(int) * live_cap));
+                    HIPCHK(dev_malloc(&d_live_off, sizeof(int64_t) * live_cap));
                 }
                 if ((size_t)ntask > live_tasks_cap) {
                     if (scr_live.ensure(c->device, SCR_GRAD_LIVE, sizeof(TaskIdx) * (size_t)ntask)) return -1;
@@ -6417,19 +6530,19 @@ extern "C" int mi_grad_eri_sharded(mi_ctx *c, const double *d_D, const double *d
         }
     hipLaunchKernelGGL(grad_reduce_copies_kernel, dim3((natm3 + 63) / 64), dim3(64), 0, st, d_gcopies, natm3, d_grad);
     HIPCHK(hipStreamSynchronize(st));
-    hipFree(d_gcopies);
+    dev_free(d_gcopies);
     if (getenv("MI355_DEBUG"))
         fprintf(stderr, "[mi355] grad_eri: variant records %.3f s, derivative quartets %.3f s\n",
                 std::chrono::duration<double>(tg1 - tg0).count(),
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count());
-    if (d_prefix) hipFree(d_prefix);
-    if (d_live_counts) hipFree(d_live_counts);
-    if (d_live_off) hipFree(d_live_off);
-    hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_shell_atom);   // (the Scratch handles go back to the per-device cache)
-    if (d_dmax) hipFree(d_dmax);
-    if (d_Mpad) hipFree(d_Mpad);
-    if (d_sh_ao) hipFree(d_sh_ao);
-    if (d_sh_n) hipFree(d_sh_n);
+    if (d_prefix) dev_free(d_prefix);
+    if (d_live_counts) dev_free(d_live_counts);
+    if (d_live_off) dev_free(d_live_off);
+    dev_free(d_comp_p); dev_free(d_comp_m); dev_free(d_shell_atom);   // (the Scratch handles go back to the per-device cache)
+    if (d_dmax) dev_free(d_dmax);
+    if (d_Mpad) dev_free(d_Mpad);
+    if (d_sh_ao) dev_free(d_sh_ao);
+    if (d_sh_n) dev_free(d_sh_n);
     return 0;
 }
 
@@ -6573,12 +6686,12 @@ extern "C" int mi_df_grad(mi_ctx *c, mi_ctx *aux, const double *d_Z3, const doub
         if (!axk[l].empty() && upload(&d_axk[l], axk[l])) return -1;
     }
     const size_t WORK_DOUBLES = (size_t)32 << 20;
-    HIPCHK(hipMalloc(&d_wp, sizeof(double) * WORK_DOUBLES));
-    HIPCHK(hipMalloc(&d_wm, sizeof(double) * WORK_DOUBLES));
-    HIPCHK(hipMalloc(&d_comp_p, sizeof(uint32_t) * 16384));
-    HIPCHK(hipMalloc(&d_comp_m, sizeof(uint32_t) * 16384));
+    HIPCHK(dev_malloc(&d_wp, sizeof(double) * WORK_DOUBLES));
+    HIPCHK(dev_malloc(&d_wm, sizeof(double) * WORK_DOUBLES));
+    HIPCHK(dev_malloc(&d_comp_p, sizeof(uint32_t) * 16384));
+    HIPCHK(dev_malloc(&d_comp_m, sizeof(uint32_t) * 16384));
     const int natm3 = c->natm * 3;
-    HIPCHK(hipMalloc(&d_gcopies, sizeof(double) * (size_t)GRAD_COPIES * natm3));
+    HIPCHK(dev_malloc(&d_gcopies, sizeof(double) * (size_t)GRAD_COPIES * natm3));
     HIPCHK(hipMemsetAsync(d_gcopies, 0, sizeof(double) * (size_t)GRAD_COPIES * natm3, st));
     size_t prefix_cap = 0;
     int64_t batch_counter = 0;
@@ -6594,9 +6707,9 @@ extern "C" int mi_df_grad(mi_ctx *c, mi_ctx *aux, const double *d_Z3, const doub
         const int64_t ntask = prefix.back();
         append_coarse_index(prefix);
         if (prefix.size() > prefix_cap) {
-            if (d_prefix) hipFree(d_prefix);
+            if (d_prefix) dev_free(d_prefix);
             prefix_cap = prefix.size() * 2;
-            HIPCHK(hipMalloc(&d_prefix, sizeof(int64_t) * prefix_cap));
+            HIPCHK(dev_malloc(&d_prefix, sizeof(int64_t) * prefix_cap));
         }
         HIPCHK(hipMemcpyAsync(d_prefix, prefix.data(), sizeof(int64_t) * prefix.size(), hipMemcpyHostToDevice, st));
         const bool has_m = l1 >= 1;
@@ -6674,14 +6787,14 @@ extern "C" int mi_df_grad(mi_ctx *c, mi_ctx *aux, const double *d_Z3, const doub
     }
     for (int q = 0; q < NPC; q++)
         for (int o = 0; o < 2; o++)
-            for (int sg = 0; sg < 2; sg++) if (d_orb[q][o][sg]) hipFree(d_orb[q][o][sg]);
+            for (int sg = 0; sg < 2; sg++) if (d_orb[q][o][sg]) dev_free(d_orb[q][o][sg]);
     for (int l = 0; l <= LMAX; l++) {
-        for (int sg = 0; sg < 2; sg++) if (d_axv[l][sg]) hipFree(d_axv[l][sg]);
-        if (d_axk[l]) hipFree(d_axk[l]);
+        for (int sg = 0; sg < 2; sg++) if (d_axv[l][sg]) dev_free(d_axv[l][sg]);
+        if (d_axk[l]) dev_free(d_axk[l]);
     }
-    hipFree(d_prim); hipFree(d_M); hipFree(d_wp); hipFree(d_wm); hipFree(d_comp_p); hipFree(d_comp_m); hipFree(d_gcopies);
-    hipFree(d_atom_o); hipFree(d_atom_a);
-    if (d_prefix) hipFree(d_prefix);
+    dev_free(d_prim); dev_free(d_M); dev_free(d_wp); dev_free(d_wm); dev_free(d_comp_p); dev_free(d_comp_m); dev_free(d_gcopies);
+    dev_free(d_atom_o); dev_free(d_atom_a);
+    if (d_prefix) dev_free(d_prefix);
     return rc;
 }
 
@@ -7098,7 +7211,7 @@ extern "C" int mi_sp2_iterate_planned(mi_ctx *c, const double *d_F, double *d_A,
         // co-residency: one workgroup per CU (79 KB of LDS each), so the grid must not exceed the CU count
         if ((int)grid.x <= c->n_cu) {
             if (!c->d_sp2_bar) {
-                HIPCHK(hipMalloc(&c->d_sp2_bar, 2 * sizeof(unsigned)));
+                HIPCHK(dev_malloc(&c->d_sp2_bar, 2 * sizeof(unsigned)));
                 HIPCHK(hipMemsetAsync(c->d_sp2_bar, 0, 2 * sizeof(unsigned), st));
                 c->sp2_bar_base = 0; c->sp2_tag = 0;
             }
