@@ -572,6 +572,14 @@ class SCF:
             if abs(err) < self.sp2_tol and abs(float(tr[0]) - target) < 1e-8:
                 self._sp2_iters = nit
                 self._sp2_validated = True
+                if (self.sp2_trace_plan and self.sp2_planned and self._sp2_plan is None and self._sp2_plannable(n)
+                        and off == 64 * nit):
+                    # cold object: the history of this checked run and the Gershgorin discs give the bounds for a plan
+                    # (one more small copy in a path that waits for the device anyway; see _plan_from_traces)
+                    h = torch.cat([ws["tr"][:off + 64], ws["b"][:2 * n]]).cpu().numpy()
+                    hh = h[:off + 64].reshape(nit + 1, 32, 2)[:, :nbd, :]
+                    self._trace_bounds = (hh[:, :, 0].sum(axis=1), hh[:, :, 1].sum(axis=1), float(h[off + 64:off + 64 + n].min()),
+                                          float(h[off + 64 + n:].max()), -1)
                 return 2.0 * ws["X"] if self._sp2_orth else 2.0 * (Li.T @ ws["X"] @ Li)
             nit = min(nit + 8, 76)
         return None
@@ -597,6 +605,11 @@ class SCF:
             # the partial traces of EVERY step (64 slots per step, 2 ceil(n/16) used): the host validates the last step and
             # reads off the first step at which the projector was already converged (-> iteration count of the next cycle)
             self._sp2_hist_shape = (nit + 1, (n + 15) // 16)
+            if self.sp2_trace_plan and self.sp2_planned and self._sp2_plan is None and self._sp2_plannable(n):
+                # cold object: the Gershgorin discs of this F' (already on the device for X_0) travel with the traces, so that the
+                # host can read spectral bounds for a purification PLAN off this run (sp2plan.bounds_from_traces)
+                self._sp2_hist_shape = (nit + 1, (n + 15) // 16, 2 * n)
+                return 2.0 * res[0], torch.cat([ws["tr"][:off + 64], ws["b"][:2 * n]])
             return 2.0 * res[0], ws["tr"][:off + 64]
         eng.sp2_init(fo.contiguous(), ws["X"], ws["b"])
         # larger N: rocBLAS DGEMM + fused update kernel per step, still without a host sync
@@ -676,11 +689,34 @@ class SCF:
         tr = torch.stack([torch.trace(X), torch.sum(X * X)])
         return scale * X, tr
 
+    # Cold object (round 3): the trace-correcting purification of a cycle leaves, for free, an interval inside the HOMO-LUMO gap
+    # (sp2plan.gap_from_traces) and Gershgorin bounds outside; once |g| is below `sp2_trace_plan_gnorm` a plan is made from them
+    # and the remaining cycles of the FIRST kernel() of an object take the planned, pipelined head too (a warm object's plan
+    # comes from its last diagonalisation and is tighter: it replaces this one at the end of the SCF).
+    sp2_trace_plan = True
+    sp2_trace_plan_gnorm = 2e-2
+    _trace_bounds = None
+    _sp2_plan_from_traces = False
+
+    def _plan_from_traces(self, nocc):
+        from . import sp2plan
+        tx, tx2, emin, emax, _cycle = self._trace_bounds
+        self._trace_bounds = None
+        b = sp2plan.bounds_from_traces(tx, tx2, emin, emax, self.sp2_inner_margin)
+        plan = sp2plan.plan(*b) if b is not None else None
+        if plan is not None:
+            self._sp2_plan = plan
+            self._sp2_plan_len = plan.shape[0] - 1
+            self._sp2_plan_gen = getattr(self, "_sp2_plan_gen", 0) + 1
+            self._sp2_plan_from_traces = True
+            self.path_counts["plan_from_traces"] = self.path_counts.get("plan_from_traces", 0) + 1
+
     def _sp2_replan(self, mo_e, nocc):
         """New plan from the eigenvalues of the (orthonormal-basis) Fock matrix just diagonalised."""
         from . import sp2plan
         e = mo_e.cpu().numpy() if torch.is_tensor(mo_e) else np.asarray(mo_e)
         self._sp2_plan = None
+        self._sp2_plan_from_traces = False
         self._sp2_plan_gen = getattr(self, "_sp2_plan_gen", 0) + 1
         if self.sp2_planned and self.eig_method == "sp2" and 0 < nocc < len(e) and self._sp2_plannable(len(e)):
             b = sp2plan.bounds_from_spectrum(e, nocc, self.sp2_inner_margin, self.sp2_outer_margin)
@@ -740,6 +776,7 @@ class SCF:
         mol = self.mol
         self._setup_once()
         eng = self.engine
+        self._trace_bounds = None
         t0 = time.time()
         if dm0 is None:
             dm0 = self.get_init_guess()
@@ -852,6 +889,9 @@ class SCF:
         if ctx["has_tr"]:
             hist = vals[pos:]
             shape = ctx["hist_shape"]
+            discs = None
+            if shape is not None and len(shape) > 2 and shape[2] and hist.size == shape[0] * 64 + shape[2]:
+                discs, hist = hist[-shape[2]:], hist[:-shape[2]]
             if shape is not None and hist.size == shape[0] * 64:
                 h = hist.reshape(shape[0], 32, 2)[:, :shape[1], :]
                 tx, tx2 = h[:, :, 0].sum(axis=1), h[:, :, 1].sum(axis=1)     # per step, partials added in index order
@@ -863,6 +903,9 @@ class SCF:
                     self._sp2_plan_len = min(self._sp2_plan.shape[0] - 1, max(first_ok + 1, 4))
                 else:
                     self._sp2_iters = max(first_ok + self.sp2_margin, 4)
+                    if discs is not None:      # trace-correcting run of a cold object: keep what a plan needs (made in _step)
+                        nd = discs.size // 2
+                        self._trace_bounds = (tx.copy(), tx2.copy(), float(discs[:nd].min()), float(discs[nd:].max()), st["cycle"])
             else:
                 trx, trx2 = self._sp2_traces(hist)
                 if not (abs(trx - trx2) < self.sp2_tol and abs(trx - nocc) < 1e-8):
@@ -890,13 +933,14 @@ class SCF:
         if not (self.pipeline and self.eig_method == "sp2" and 0 < nocc < n and not self.level_shift
                 and st["cycle"] + 1 >= self.diis_start_cycle and st["diis"].count > 0):
             return None
+        use_gnorm = self.sp2_trace_plan_gnorm if self._sp2_plan_from_traces else self.sp2_plan_gnorm
         planned = (self.sp2_planned and self._sp2_plannable(n) and self._sp2_plan is not None
-                   and st.get("gnorm", 0.0) <= self.sp2_plan_gnorm)
+                   and st.get("gnorm", 0.0) <= use_gnorm)
         # a COLD object (first kernel() of the object: no plan yet, see `sp2_plan_inloop`) pipelines too: the trace-correcting
         # purification needs no spectral bounds, only a pass count -- the one the previous cycle needed plus a margin that is
         # generous while the spectrum still moves (a pass costs 7 us, a redone cycle a whole Fock build)
         cold = (not planned and self.cold_pipeline and self._sp2_validated and n <= self.sp2_fused_max and self.sp2_fused
-                and (self._sp2_plan is None or st.get("gnorm", 0.0) > self.sp2_plan_gnorm))
+                and (self._sp2_plan is None or st.get("gnorm", 0.0) > use_gnorm))
         if not (planned or cold):
             return None
         if planned and self.graph_front:
@@ -1005,7 +1049,7 @@ class SCF:
             # `sp2_plan_gnorm` the trace-correcting purification runs instead -- it needs no bounds -- and the plan is made once,
             # when the SCF has settled; warm starts (dm0 from a nearby geometry) plan at their first cycle.
             early = planned_ok and self._sp2_plan is None and (st.get("gnorm", 0.0) > self.sp2_plan_gnorm or not self.sp2_plan_inloop)
-            settled = st.get("gnorm", 0.0) <= self.sp2_plan_gnorm
+            settled = st.get("gnorm", 0.0) <= (self.sp2_trace_plan_gnorm if self._sp2_plan_from_traces else self.sp2_plan_gnorm)
             if planned_ok and self._sp2_plan is not None and settled and not st.get("_redo"):
                 dmo, tr_dev = self._sp2_planned_async(fo, nocc)
                 self._sp2_planned_pass = True
@@ -1058,6 +1102,11 @@ class SCF:
         e_prev = st["e_tot"]
         ctx = self._after_density_launch(st, dm, st["cycle"] + 1, sp2_tr=tr_dev, hist_shape=hist_shape, projector=True)
         nxt = self._front(st) if (use_diis and not want_mo) else None
+        if (self.sp2_trace_plan and self._sp2_plan is None and self._trace_bounds is not None and use_diis and not want_mo
+                and st.get("gnorm", 1.0) <= self.sp2_trace_plan_gnorm):
+            # cold object, SCF settling: the plan for the cycles to come is made HERE, from the traces of the last checked
+            # purification, while the device is busy with this cycle's Fock build and the head of the next (1 ms of host time)
+            self._plan_from_traces(st["nocc"])
         ok = self._after_density_finish(st, ctx, e_prev, nocc)
         if not ok:
             # the optimistic purification had not converged (planned path: the spectrum left the planned bounds): roll the DIIS

@@ -73,3 +73,46 @@ def bounds_from_spectrum(e, nocc, inner_margin=0.15, outer_margin=2.0):
     homo, lumo = float(e[nocc - 1]), float(e[nocc])
     d = min(inner_margin, 0.25 * (lumo - homo))
     return float(e[0]) - outer_margin, float(e[-1]) + outer_margin, homo + d, lumo - d
+
+
+def gap_from_traces(tx, tx2, emin, emax, wmin=1e-9, wmax=0.2):
+    """(homo_ub, lumo_lb): an interval INSIDE the HOMO-LUMO gap of the matrix a trace-correcting SP2 run has just purified, from
+    the traces it recorded anyway -- tx[i] = tr X_i, tx2[i] = tr X_i^2, X_0 = (emax I - F) / (emax - emin), X_{i+1} = X_i^2 or
+    2 X_i - X_i^2.  Every eigenvalue x of X_i lies in [0, 1], so x (1 - x) <= w_i = tr(X_i - X_i^2): the spectrum of X_i avoids
+    (u_i, 1 - u_i), u_i = (1 - sqrt(1 - 4 w_i)) / 2.  Both SP2 maps increase on [0, 1], so the hole pulls back through their
+    inverses to a hole (a, b) of X_0, i.e. no orbital energy in (emax - b W, emax - a W) (the idea of Rubensson & Niklasson's
+    interior-eigenvalue estimates from purification, here with the plain trace instead of the Frobenius norm [MEM]).  Every step
+    gives a valid hole; the late ones (small w_i, still above rounding) give the widest.  None if no step qualifies."""
+    tx, tx2 = np.asarray(tx, dtype=np.float64), np.asarray(tx2, dtype=np.float64)
+    n = len(tx)
+    # which map step i -> i + 1 took: the one whose trace reproduces tx[i + 1]
+    sq = np.abs(tx2[:-1] - tx[1:]) <= np.abs(2.0 * tx[:-1] - tx2[:-1] - tx[1:])
+    w = tx - tx2
+    best = None
+    for i in range(n):
+        if not (wmin < w[i] < wmax):
+            continue
+        u = 2.0 * w[i] / (1.0 + np.sqrt(1.0 - 4.0 * w[i]))
+        a, b = u, 1.0 - u
+        for j in range(i - 1, -1, -1):
+            if sq[j]:
+                a, b = np.sqrt(a), np.sqrt(b)
+            else:                                   # y = 2 x - x^2  ->  x = 1 - sqrt(1 - y) = y / (1 + sqrt(1 - y))
+                a, b = a / (1.0 + np.sqrt(1.0 - a)), b / (1.0 + np.sqrt(1.0 - b))
+        if b > a and (best is None or b - a > best[1] - best[0]):
+            best = (a, b)
+    if best is None:
+        return None
+    wd = emax - emin
+    return emax - best[1] * wd, emax - best[0] * wd
+
+
+def bounds_from_traces(tx, tx2, emin, emax, inner_margin=0.15, outer_margin=0.5):
+    """(lo, hi, homo_in, lumo_in) for `plan` from a trace-correcting run (see gap_from_traces): Gershgorin bounds outside (they
+    move with the matrix, so a small margin), the hole shrunk by `inner_margin` (a quarter of its width at most) inside."""
+    g = gap_from_traces(tx, tx2, emin, emax)
+    if g is None:
+        return None
+    homo_ub, lumo_lb = g
+    d = min(inner_margin, 0.25 * (lumo_lb - homo_ub))
+    return emin - outer_margin, emax + outer_margin, homo_ub + d, lumo_lb - d

@@ -13,6 +13,11 @@ for rep in range(2):
     mf = RHF(mol)
     if "--no-cold-pipeline" in sys.argv:
         mf.cold_pipeline = False
+    if "--no-trace-plan" in sys.argv:
+        mf.sp2_trace_plan = False
+    for a in sys.argv:
+        if a.startswith("--trace-gnorm="):
+            mf.sp2_trace_plan_gnorm = float(a.split("=")[1])
     if rep == 1:
         mf._eng = eng      # second object: libraries warm, ERIs resident; still a cold OBJECT (no plan)
     st = mf._start(None)
@@ -24,4 +29,4 @@ for rep in range(2):
         print(f"rep {rep} cycle {i + 1}: {1e3 * (time.perf_counter() - t0):7.2f} ms  front={had_front} planned={mf._sp2_planned_pass} iters={mf._sp2_iters} "
               f"redo={getattr(mf, 'n_redo', 0)} |g|={st['gnorm']:.2e} E={st['e_tot']:.10f}", flush=True)
     torch.cuda.synchronize()
-    print(f"rep {rep}: 9 cycles {1e3 * (time.perf_counter() - t_all):.2f} ms")
+    print(f"rep {rep}: 9 cycles {1e3 * (time.perf_counter() - t_all):.2f} ms  plan_len={getattr(mf, '_sp2_plan_len', None)} paths={mf.path_counts}")
