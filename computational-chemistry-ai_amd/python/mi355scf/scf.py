@@ -694,6 +694,7 @@ class SCF:
     # and the remaining cycles of the FIRST kernel() of an object take the planned, pipelined head too (a warm object's plan
     # comes from its last diagonalisation and is tighter: it replaces this one at the end of the SCF).
     sp2_trace_plan = True
+    sp2_first_passes = 48     # passes of the very first (optimistic) purification of an object; 0: checked path
     sp2_trace_plan_gnorm = 2e-2
     _trace_bounds = None
     _sp2_plan_from_traces = False
@@ -898,6 +899,7 @@ class SCF:
                 ok = (np.abs(tx - tx2) < self.sp2_tol) & (np.abs(tx - nocc) < 1e-8)
                 if not ok[-1]:
                     return False
+                self._sp2_validated = True
                 first_ok = int(np.argmax(ok))            # steps beyond it were not needed for this Fock matrix
                 if getattr(self, "_sp2_planned_pass", False):
                     self._sp2_plan_len = min(self._sp2_plan.shape[0] - 1, max(first_ok + 1, 4))
@@ -939,7 +941,7 @@ class SCF:
         # a COLD object (first kernel() of the object: no plan yet, see `sp2_plan_inloop`) pipelines too: the trace-correcting
         # purification needs no spectral bounds, only a pass count -- the one the previous cycle needed plus a margin that is
         # generous while the spectrum still moves (a pass costs 7 us, a redone cycle a whole Fock build)
-        cold = (not planned and self.cold_pipeline and self._sp2_validated and n <= self.sp2_fused_max and self.sp2_fused
+        cold = (not planned and self.cold_pipeline and (self._sp2_validated or self.sp2_first_passes) and n <= self.sp2_fused_max and self.sp2_fused
                 and (self._sp2_plan is None or st.get("gnorm", 0.0) > use_gnorm))
         if not (planned or cold):
             return None
@@ -953,6 +955,8 @@ class SCF:
         else:
             keep = self._sp2_iters
             self._sp2_iters = min(keep + (self.cold_margin if st.get("gnorm", 0.0) > self.sp2_plan_gnorm else 0), 72)
+            if not self._sp2_validated:      # head of cycle 2, queued before cycle 1's first purification has been validated
+                self._sp2_iters = self.sp2_first_passes
             dmo, tr_dev = self._sp2_fused_async(fo, nocc)
             self._sp2_iters = keep
         shape, self._sp2_hist_shape = self._sp2_hist_shape, None
@@ -1061,10 +1065,13 @@ class SCF:
                 dmo = self._density_sp2(fo, nocc, orth=True)
                 took("checked_unsettled_with_plan")
             elif early and st.get("gnorm", 0.0) > self.sp2_plan_gnorm:
-                if self.cold_pipeline and self._sp2_validated and not st.get("_redo") and n <= self.sp2_fused_max and self.sp2_fused:
-                    # optimistic: last count + a generous margin, validated with the cycle's scalars (no host sync here)
+                if (self.cold_pipeline and (self._sp2_validated or self.sp2_first_passes) and not st.get("_redo")
+                        and n <= self.sp2_fused_max and self.sp2_fused):
+                    # optimistic: last count + a generous margin, validated with the cycle's scalars (no host sync here).  The
+                    # very first purification of an object has no count yet: `sp2_first_passes` in one go instead of the checked
+                    # path's 24 / 32 / 40 with a host round trip each (benzene/cc-pVTZ needs 34); too few -> the redo below
                     keep = self._sp2_iters
-                    self._sp2_iters = min(keep + self.cold_margin, 72)
+                    self._sp2_iters = min(keep + self.cold_margin, 72) if self._sp2_validated else self.sp2_first_passes
                     dmo, tr_dev = self._sp2_fused_async(fo, nocc)
                     self._sp2_iters = keep
                 else:
