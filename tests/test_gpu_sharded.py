@@ -311,3 +311,61 @@ def test_two_rank_density_fitting_shards_the_auxiliary_index():
     for r in res:
         assert r[6]["all_reduce"] == r[6]["fock_builds"], r[6]
         assert np.abs(np.array(r[5]) - g1).max() < 1e-8 and np.abs(g1).max() > 1e-3
+
+
+def _hess_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "computational-chemistry-ai_amd", "python"))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch
+        from mi355scf import parallel
+        from pyscf import gto, scf, hessian
+        torch.cuda.set_device(0)
+        parallel.init("gloo")
+        mol = gto.Mole()
+        mol.atom, mol.basis, mol.verbose = MOLECULES["h2o"], "6-31G", 0
+        mol.build()
+        mf = scf.RHF(mol)
+        mf.conv_tol = 1e-11
+        mf.kernel()
+        h = hessian.RHF(mf).distribute(rank, world)
+        H = h.kernel()
+        q.put((rank, H.tolist(), h.dipole_deriv.tolist()))
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def test_two_rank_replica_hessian_matches_single():
+    """`Hessian.distribute(rank, nranks)`: the displaced coordinates are dealt to the ranks (whole SCF + gradient per point on
+    each rank's own object, no collective inside a point), one all-reduce joins the rows: every rank ends with the Hessian and the
+    dipole derivatives of the one-process run."""
+    from pyscf import gto, scf, hessian
+    mol = gto.Mole()
+    mol.atom, mol.basis, mol.verbose = MOLECULES["h2o"], "6-31G", 0
+    mol.build()
+    mf = scf.RHF(mol)
+    mf.conv_tol = 1e-11
+    mf.kernel()
+    h1 = hessian.RHF(mf)
+    H1 = h1.kernel()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_hess_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert not any(r[1] == "error" for r in res), [r[2] for r in res if r[1] == "error"]
+    for r in res:
+        # (each displaced SCF is converged to 1e-10 from a different starting density: 1e-7 in the gradients, 1e-5 here)
+        assert np.abs(np.array(r[1]) - H1).max() < 5e-5, np.abs(np.array(r[1]) - H1).max()
+        assert np.abs(np.array(r[2]) - h1.dipole_deriv).max() < 5e-4      # (first order in the density error of each displaced SCF)
+    assert np.abs(H1).max() > 0.1
