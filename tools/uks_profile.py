@@ -2,7 +2,7 @@
 """cProfile of the second kernel() of a UKS object (benzene cation B3LYP/cc-pVTZ): the plain UHF/UKS loop still syncs ~9 times per
 cycle (`.cpu()` reads), unlike the single-readback RHF/RKS step.   python tools/uks_profile.py"""
 import cProfile, pstats, sys, os
-sys.path.insert(0, "computational-chemistry-ai_amd/python")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "computational-chemistry-ai_amd", "python"))
 import torch
 from mi355scf.mole import Mole
 from mi355scf.uks import UKS
