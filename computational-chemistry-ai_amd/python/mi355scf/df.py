@@ -60,6 +60,8 @@ def tri_inv_lower(L, base=2048):
     if n <= base:
         return torch.linalg.solve_triangular(L, torch.eye(n, dtype=L.dtype, device=L.device), upper=False)
     h = (n // 2 + 63) // 64 * 64
+    if h >= n:
+        h = n // 2
     out = torch.zeros_like(L)
     Ai = tri_inv_lower(L[:h, :h].contiguous(), base)
     Di = tri_inv_lower(L[h:, h:].contiguous(), base)

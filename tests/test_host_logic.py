@@ -345,3 +345,60 @@ def test_planned_purification_reaches_the_projector_in_about_twenty_quadratics()
     assert np.abs(X - P).max() < 1e-10
     # ... and bounds without a gap give no plan
     assert sp2plan.plan(lo, hi, 0.2, 0.1) is None
+
+
+def test_gap_interval_from_sp2_traces_lies_inside_the_true_gap():
+    """sp2plan.gap_from_traces: from the (tr X_i, tr X_i^2) sequence of a trace-correcting SP2 run alone, an energy interval that
+    contains no orbital energy and brackets the Fermi level -- also with a degenerate HOMO / LUMO -- and a plan made from it
+    purifies the matrix (the cold-object path of SCF._plan_from_traces)."""
+    from mi355scf import sp2plan
+    rng = np.random.default_rng(7)
+    for n, nocc, degenerate in ((60, 12, False), (80, 21, True), (40, 5, False)):
+        occ = np.sort(rng.uniform(-11.0, -0.35, nocc))
+        vir = np.sort(rng.uniform(0.12, 30.0, n - nocc))
+        if degenerate:
+            occ[-2] = occ[-1]
+            vir[1] = vir[0]
+        e = np.concatenate([occ, vir])
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        f = q @ np.diag(e) @ q.T
+        r = np.abs(f).sum(axis=1) - np.abs(np.diag(f))
+        emin, emax = (np.diag(f) - r).min(), (np.diag(f) + r).max()
+        x = (emax * np.eye(n) - f) / (emax - emin)
+        tx, tx2 = [np.trace(x)], [np.trace(x @ x)]
+        for _ in range(60):
+            x2 = x @ x
+            x = x2 if abs(np.trace(x2) - nocc) < abs(2 * np.trace(x) - np.trace(x2) - nocc) else 2 * x - x2
+            tx.append(np.trace(x)); tx2.append(np.trace(x @ x))
+        assert abs(tx[-1] - nocc) < 1e-8
+        homo_ub, lumo_lb = sp2plan.gap_from_traces(tx, tx2, emin, emax)
+        assert occ[-1] <= homo_ub < lumo_lb <= vir[0], (occ[-1], homo_ub, lumo_lb, vir[0])
+        assert lumo_lb - homo_ub > 0.5 * (vir[0] - occ[-1])          # and it is not uselessly narrow
+        b = sp2plan.bounds_from_traces(tx, tx2, emin, emax)
+        coef = sp2plan.plan(*b)
+        assert coef is not None and coef.shape[0] - 1 <= 45
+        y = coef[0][1] * f + coef[0][2] * np.eye(n)
+        for a_, b_, c_ in coef[1:]:
+            y = a_ * (y @ y) + b_ * y + c_ * np.eye(n)
+        p = q[:, :nocc] @ q[:, :nocc].T
+        assert np.abs(y - p).max() < 1e-9
+    assert sp2plan.gap_from_traces([3.0, 3.0], [1.0, 1.0], -1.0, 1.0) is None      # no step with a small enough tr(X - X^2)
+
+
+def test_density_fitting_host_helpers():
+    """df.pivoted_cholesky (rank-revealing factor of an SCF density, None for anything else) and df.tri_inv_lower (blocked
+    inverse of a Cholesky factor) on the CPU."""
+    import torch
+    from mi355scf.df import pivoted_cholesky, tri_inv_lower
+    g = torch.Generator().manual_seed(3)
+    c = torch.randn(90, 11, generator=g, dtype=torch.float64)
+    d = 2.0 * c @ c.T
+    for rank in (11, 14):                     # exact rank, and a larger hint (beta spin of an open shell)
+        lf = pivoted_cholesky(d, rank)
+        assert lf is not None and lf.shape == (90, rank) and (lf @ lf.T - d).abs().max() < 1e-11
+    assert pivoted_cholesky(d, 9) is None                                   # rank too small: remainder not negligible
+    a = torch.randn(90, 90, generator=g, dtype=torch.float64)
+    assert pivoted_cholesky(a + a.T, 11) is None                            # indefinite
+    s = a @ a.T + 90.0 * torch.eye(90, dtype=torch.float64)
+    lo = torch.linalg.cholesky(s)
+    assert (tri_inv_lower(lo, base=16) @ lo - torch.eye(90, dtype=torch.float64)).abs().max() < 1e-12
