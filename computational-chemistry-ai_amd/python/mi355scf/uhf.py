@@ -149,6 +149,47 @@ class UHF(SCF):
             return self._kernel_fast(dm0)
         return self._kernel_plain(dm0)
 
+    # Plain loop (round 3): once a spin's checked, trace-correcting purification has run with |g| below `sp2_trace_plan_gnorm`, its
+    # trace history gives the bounds of a purification PLAN for that spin (sp2plan.bounds_from_traces, as in the closed-shell
+    # cold path) and the following cycles run the ~21 planned passes instead of the 40-60 of the recursion; the result is checked
+    # on the host like the recursion's (this loop synchronises per spin anyway) and a failed check drops the plan.
+    def _planned_spin_density(self, fo, no, state, gnorm):
+        plan = state.get("plan")
+        n = fo.shape[0]
+        if plan is None or not (self.sp2_planned and self.sp2_trace_plan and n <= self.sp2_fused_max and self.sp2_fused):
+            return None
+        keep = (self._sp2_plan, getattr(self, "_sp2_plan_len", 0))
+        try:
+            self._sp2_plan, self._sp2_plan_len = plan["coef"], plan["len"]
+            res, tr_dev = self._sp2_planned_async(fo, no, scale=2.0)
+            shape, self._sp2_hist_shape = self._sp2_hist_shape, None
+        finally:
+            self._sp2_plan, self._sp2_plan_len = keep
+        hist = tr_dev.cpu().numpy()
+        if shape is None or hist.size != shape[0] * 64:
+            state["plan"] = None
+            return None
+        h = hist.reshape(shape[0], 32, 2)[:, :shape[1], :]
+        tx, tx2 = h[:, :, 0].sum(axis=1), h[:, :, 1].sum(axis=1)
+        ok = (np.abs(tx - tx2) < self.sp2_tol) & (np.abs(tx - no) < 1e-8)
+        if not ok[-1]:
+            state["plan"] = None            # the spectrum left the planned window: checked recursion, new plan from its traces
+            return None
+        plan["len"] = min(plan["coef"].shape[0] - 1, max(int(np.argmax(ok)) + 1, 4))
+        self.path_counts = getattr(self, "path_counts", {})
+        self.path_counts["planned_spin"] = self.path_counts.get("planned_spin", 0) + 1
+        return res.clone()                  # (a view of the ping-pong buffers the other spin is about to reuse)
+
+    def _plan_spin_from_traces(self, state, gnorm):
+        tb, self._trace_bounds = self._trace_bounds, None
+        if tb is None or not (self.sp2_planned and self.sp2_trace_plan) or gnorm > self.sp2_trace_plan_gnorm:
+            return
+        from . import sp2plan
+        b = sp2plan.bounds_from_traces(tb[0], tb[1], tb[2], tb[3], self.sp2_inner_margin)
+        coef = sp2plan.plan(*b) if b is not None else None
+        if coef is not None:
+            state["plan"] = dict(coef=coef, len=coef.shape[0] - 1)
+
     def _seed_plans(self, mo_e):
         """Purification plans of both spins from the orbital energies of a finished SCF (for the next kernel() of this object)."""
         n = self.engine.nao
@@ -484,7 +525,12 @@ class UHF(SCF):
                     continue
                 fo = (Li @ Fx[s_] @ Li.T).contiguous()
                 self._sp2_iters, self._sp2_validated = sp2_state[s_]["_sp2_iters"], sp2_state[s_]["_sp2_validated"]
-                dmo = self._density_sp2(fo, no, orth=True)
+                g_prev = gnorm if cycle > 0 else 1.0e9          # (no orbital gradient before the first cycle has finished)
+                dmo = self._planned_spin_density(fo, no, sp2_state[s_], g_prev)
+                if dmo is None:
+                    self._trace_bounds = None
+                    dmo = self._density_sp2(fo, no, orth=True)
+                    self._plan_spin_from_traces(sp2_state[s_], g_prev)
                 sp2_state[s_].update(_sp2_iters=self._sp2_iters, _sp2_validated=self._sp2_validated)
                 if dmo is None:      # purification did not converge (vanishing gap): diagonalise this spin
                     e_, c_ = torch.linalg.eigh(fo)
