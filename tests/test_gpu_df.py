@@ -116,21 +116,26 @@ def test_df_derivative_integrals_match_oracle(name, basis):
     aux_eng.close()
 
 
-@pytest.mark.parametrize("method", ["RHF", "B3LYP", "UHF", "PBE"])
+@pytest.mark.parametrize("method", ["RHF", "B3LYP", "UHF", "PBE", "UB3LYP"])
 def test_density_fitted_gradient_matches_finite_difference_of_the_fitted_energy(method):
     """`mf.density_fit().nuc_grad_method().kernel()` against central differences of the fitted SCF energy: 1e-6 for HF; for the
     functionals the analytic gradient leaves out the grid-weight response (as PySCF does by default [MEM]; 2e-4, see
     test_gpu_grad), which the exact-integral gradient shares: there g_DF - g_exact is compared with FD(E_DF - E_exact)."""
     from pyscf import gto, scf, dft
     ks = method not in ("RHF", "UHF")
+    open_shell = method.startswith("U")
 
     def make(atom, fit, unit="Angstrom"):
         mol = gto.Mole()
         mol.atom, mol.basis, mol.verbose, mol.unit = atom, "6-31G(d)", 0, unit
-        if method == "UHF":
+        if open_shell:
             mol.charge, mol.spin = 1, 1
         mol.build()
-        mf = scf.RHF(mol) if method == "RHF" else scf.UHF(mol) if method == "UHF" else dft.RKS(mol, xc=method)
+        if method == "UB3LYP":
+            mf = dft.UKS(mol)
+            mf.xc = "B3LYP"
+        else:
+            mf = scf.RHF(mol) if method == "RHF" else scf.UHF(mol) if method == "UHF" else dft.RKS(mol, xc=method)
         if fit:
             mf = mf.density_fit()
         mf.conv_tol = 1e-12
@@ -140,7 +145,7 @@ def test_density_fitted_gradient_matches_finite_difference_of_the_fitted_energy(
     assert mf.converged
     g = mf.nuc_grad_method().kernel()
     # exchange densities through the low-rank factor of each spin density == the dense N^2 N_aux^2 route
-    dms = mf._dm if method != "UHF" else [mf._dm[0], mf._dm[1]]
+    dms = mf._dm if not open_shell else [mf._dm[0], mf._dm[1]]
     ga, gb = (mf.with_df.grad_jk(dms, 1.0, factorize=f).cpu().numpy() for f in (True, False))
     assert np.abs(ga - gb).max() < 1e-10 and np.abs(ga).max() > 1e-2
     if ks:
