@@ -42,7 +42,9 @@ void mi_ctx_destroy(mi_ctx *ctx);
 int mi_ctx_nao(const mi_ctx *ctx);
 
 /* A destroyed context parks its (possibly ~100 GB) tile store for reuse by the next context on the same
- * device (geometry optimisation); this frees the parked stores. */
+ * device (geometry optimisation); hand-over buffers, task lists and the pool of small device buffers are kept per device
+ * as well.  This frees all of them.  (The library expects ONE host thread per device at a time: a second context working on
+ * the same device from another thread gets private scratch buffers, but parked blocks are shared.) */
 void mi_release_cache(void);
 
 /* Tunables (project-defined, no reference counterpart).  Unknown keys are an error.
@@ -58,6 +60,10 @@ void mi_release_cache(void);
  *   "jk_pipe"     half-tile software pipeline for full-row tiles (-1 auto)
  *   "jk_pair"     n_dm = 2: one pass with two waves per work item (-1 = for stores > 16 GB, 0 = one pass per density, 1 = always)
  *   "grad_dtol"   derivative quartets with q_ab q_cd max|G| below this are skipped (default 1e-13, 0 = Schwarz only)
+ *   "grad_live"   1 (default): that test runs once per class pair and the derivative launches walk the compacted list of live
+ *                 quartets; 0: every launch screens per wave
+ *   "grad_rows", "grad_rows_min", "grad_rows_g32"  row gradient kernel for the mid / high classes (1 = on, default), for
+ *                 derivative blocks of at least this many rows (20), two quartets per wave up to 64 rows (1)
  *   "vmat_xcd"    xc_vmat: XCD-aware workgroup order (1, default: the tiles of one split share an XCD's L2; 0: natural order)
  *   "vmat_wgs"    xc_vmat: workgroups aimed at by the split over the grid points (0 = 1024, two full rounds; -1 = round-1 formula)
  *   "sp2_persist" planned purification as ONE resident launch with grid barriers (0 = one launch per pass, default and faster;
