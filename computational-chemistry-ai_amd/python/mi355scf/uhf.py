@@ -519,9 +519,11 @@ class UHF(SCF):
                 e_, c_ = orbitals(Fx)
                 return density(c_), (e_, c_)
             out = []
+            xs = []        # spin projectors X_s in the orthonormal basis (UKS: rho_s from a low-rank factor, `_xc_projector_pair`)
             for s_, no in ((0, na), (1, nb)):
                 if no == 0:
                     out.append(torch.zeros(n, n, dtype=torch.float64, device=eng.device))
+                    xs.append(out[-1])
                     continue
                 fo = (Li @ Fx[s_] @ Li.T).contiguous()
                 self._sp2_iters, self._sp2_validated = sp2_state[s_]["_sp2_iters"], sp2_state[s_]["_sp2_validated"]
@@ -536,8 +538,12 @@ class UHF(SCF):
                     e_, c_ = torch.linalg.eigh(fo)
                     co = Li.T @ c_[:, :no]
                     out.append(co @ co.T)
+                    xs = None
                 else:
                     out.append(0.5 * (Li.T @ dmo @ Li))
+                    if xs is not None:
+                        xs.append(0.5 * dmo)
+            self._plain_projectors = xs
             return torch.stack(out), None
 
         def commutator(Fx, dmx):
@@ -550,10 +556,19 @@ class UHF(SCF):
             Fx = diis.update(F, err) if cycle + 1 >= self.diis_start_cycle else F
             if self.level_shift:   # F_s + shift (S - S D_s S): virtual space of each spin raised (AO form of PySCF's level_shift)
                 Fx = Fx + self.level_shift * (S.unsqueeze(0) - torch.stack([S @ dm[s_] @ S for s_ in range(2)]))
+            self._plain_projectors = None
             dm, mo = new_density(Fx)
             if mo is not None:
                 mo_e, mo_c = mo
+            # purified spin densities are projectors of known rank: UKS takes rho_s from their low-rank factors (one pass over
+            # the AO values instead of an N x N x n_grid product per spin), exactly as in the fast loop
+            xs = self._plain_projectors
+            self._xc_projector_pair = (dm, xs, (na, nb)) if xs is not None else None
             F, e_el = self._fock_pair(dm)
+            if self._xc_projector_pair is not None and not bool(torch.isfinite(e_el).all()):
+                self._xc_projector_pair = None          # a failed factorisation poisons itself with NaN: full densities instead
+                F, e_el = self._fock_pair(dm)
+            self._xc_projector_pair = None
             err = commutator(F, dm)
             # |g| = |F_vo| of both spins = |[F', D']|_F / sqrt(2) in the orthonormal basis (D' is a projector)
             eo = torch.stack([Li @ err[s_] @ Li.T for s_ in range(2)])
